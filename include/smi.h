@@ -1,0 +1,156 @@
+/* smi.h -- C ABI of libsmi_hip.so: the MI355X-native (gfx950) hot path of the concept-slider LoRA trainer.
+ *
+ * The reference (ntc-ai/sliders-conceptmod) is pure Python and has no FFI of its own; the seam this library sits
+ * under is the duck-typed model call the reference's step helpers make,
+ *     unet(sample, timestep, encoder_hidden_states=..., added_cond_kwargs=...).sample
+ * (conceptmod/textsliders/train_util.py:290-294 and :471-476), together with the autograd backward that
+ * `loss.backward()` triggers through it (train_lora.py:298, train_lora_xl.py:348) and the elementwise step ops
+ * around it.  Each entry point below names the reference code it replaces.  The Python binding a maintainer adds on
+ * the reference side is shown in INTEGRATION.md (ctypes; the in-tree one is sliders_conceptmod_amd/_native.py).
+ *
+ * Conventions: plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host"; the caller
+ * owns all memory (weights, LoRA parameters, gradients, latents, the workspace) and the library borrows it for the
+ * duration of a call (the workspace: for the lifetime of the engine).  All work is enqueued on the `stream` given at
+ * creation (a hipStream_t passed as void*, NULL = default stream); no call synchronises with the host.  Every
+ * function returns 0 on success and a negative value on error; smi_last_error() then returns a message.
+ * Nothing throws across the boundary.
+ */
+#ifndef SMI_H_
+#define SMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMI_MAX_LEVELS 8
+#define SMI_DTYPE_F16 0
+#define SMI_DTYPE_BF16 1
+
+/* Architecture of the diffusers UNet2DConditionModel being replaced (the values of its public config). */
+typedef struct smi_unet_config {
+  int dtype;                 /* storage / MFMA input type of weights and activations; accumulation is always fp32 */
+  int in_channels;           /* 4 */
+  int out_channels;          /* 4 */
+  int n_levels;              /* len(block_out_channels) */
+  int block_out_channels[SMI_MAX_LEVELS];
+  int down_has_attn[SMI_MAX_LEVELS]; /* CrossAttnDownBlock2D (1) or DownBlock2D (0) */
+  int up_has_attn[SMI_MAX_LEVELS];   /* CrossAttnUpBlock2D (1) or UpBlock2D (0), in up_blocks order */
+  int layers_per_block;
+  int transformer_layers[SMI_MAX_LEVELS]; /* per down level */
+  int num_heads[SMI_MAX_LEVELS];          /* per down level (diffusers "attention_head_dim") */
+  int mid_transformer_layers;
+  int cross_attention_dim;
+  int norm_num_groups;
+  int use_linear_projection;
+  int addition_embed;        /* 1 = SD-XL "text_time" conditioning */
+  int addition_time_embed_dim;
+  int projection_class_embeddings_input_dim;
+} smi_unet_config;
+
+/* One frozen weight tensor, named as in the diffusers state_dict ("down_blocks.0.resnets.0.conv1.weight"),
+ * already in `dtype`, contiguous, torch layout. */
+typedef struct smi_weight {
+  const char* name;
+  const void* data;
+  int ndim;
+  int64_t shape[4];
+} smi_weight;
+
+/* One LoRA-adapted Linear (reference: LoRAModule, conceptmod/textsliders/lora.py:76-138).
+ * `target` is the dotted module path ("down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q").
+ * lora_down.weight [rank, in] lives at down_flat + off_down, lora_up.weight [out, rank] at up_flat + off_up
+ * (element offsets into the two flat fp32 buffers passed per call). scale = alpha / rank (lora.py:118-119). */
+typedef struct smi_lora_site {
+  const char* target;
+  int64_t off_down;
+  int64_t off_up;
+  int rank;
+  float scale;
+} smi_lora_site;
+
+typedef struct smi_engine smi_engine;
+
+const char* smi_last_error(void);
+
+/* Bytes of device workspace an engine needs for UNet batch `batch` (= 2B of the reference's CFG-doubled batch,
+ * train_util.py:285), latent h x w, context length ctx_len, and the given set of adapted layers. */
+int smi_workspace_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int h, int w,
+                        int ctx_len, size_t* bytes);
+
+/* Builds the engine: packs the frozen weights into MFMA-friendly layouts inside `workspace` (transposed copies for
+ * the activation-gradient GEMMs, (ky,kx,ci)-ordered conv filters, fused q|k|v) and lays out the activation arenas.
+ * Replaces: unet.to(device, dtype); unet.requires_grad_(False); unet.eval(); LoRANetwork(...).apply_to()
+ * (train_lora.py:67-78). */
+int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weights, const smi_lora_site* sites,
+               int n_sites, int batch, int h, int w, int ctx_len, void* workspace, size_t workspace_bytes,
+               void* stream, smi_engine** out);
+void smi_destroy(smi_engine* e);
+
+/* eps = unet(sample, t, ctx[, text_embeds, time_ids]).sample           (train_util.py:290-294, 471-476)
+ *   sample      f32 [n, 4, h, w]  (NCHW, already scale_model_input-ed)
+ *   ctx         T   [n, ctx_len, cross_attention_dim]
+ *   text_embeds T   [n, P] or NULL ; time_ids f32 [n, 6] or NULL        (SD-XL added_cond_kwargs)
+ *   lora_down_flat / lora_up_flat: flat fp32 LoRA parameters, NULL or multiplier == 0 -> adaptor off
+ *                 (LoRANetwork.__exit__, lora.py:299-301); multiplier = 1.0 * lora_scale inside `with network`.
+ *   save_for_backward != 0 keeps the activations the backward needs (the pass that runs with grad enabled).
+ *   eps_out     f32 [n, 4, h, w]
+ * n may be smaller than the creation batch. */
+int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, const void* ctx,
+                     const void* text_embeds, const float* time_ids, const float* lora_down_flat,
+                     const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out);
+
+/* Backward of the last save_for_backward forward: accumulates (+=) d(loss)/d(lora_down), d(loss)/d(lora_up) into
+ * the flat fp32 gradient buffers (same offsets as the parameters).  Activation gradients are propagated only as far
+ * as the first adapted layer; no frozen-weight gradients exist (unet.requires_grad_(False), train_lora.py:69).
+ * Replaces loss.backward() through the UNet (train_lora.py:298). */
+int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat, float* d_lora_up_flat);
+
+/* out[i] = u[i] + g * (t[i] - u[i]) over the two halves of a CFG-doubled prediction   (train_util.py:297-300) */
+int smi_cfg_combine(const float* eps_2n, float* out_n, int64_t n_half, float guidance_scale, void* stream);
+
+/* PromptEmbedsPair.loss (prompt_util.py:134-174): loss = mean((target - (neutral + sign_eta*(positive-negative)))^2)
+ * sign_eta = +eta for "enhance", -eta for "erase".  Writes the scalar to loss_out[0] and, if dtarget != NULL,
+ * d(loss)/d(target).  scratch: >= 256 floats. */
+int smi_slider_loss(const float* target, const float* positive, const float* neutral, const float* negative,
+                    float sign_eta, int64_t n, float* loss_out, float* dtarget, float* scratch, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) (train_lora_xl.py:349; max_norm <= 0: no clipping) followed by
+ * one torch.optim.AdamW step (train_lora_xl.py:104,350; train_util.py:1040) over flat fp32 buffers.
+ * step counts from 1.  scratch: >= 1025 floats. */
+int smi_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float max_norm, float* scratch,
+                   void* stream);
+
+/* x = c_x * x + c_eps * eps + c_noise * noise   -- the update of scheduler.step(...).prev_sample
+ * (train_util.py:324,705) for DDIM (eta = 0; noise = NULL) and Euler-ancestral; coefficients computed on the host. */
+int smi_sched_step(float* x, const float* eps, const float* noise, float c_x, float c_eps, float c_noise, int64_t n,
+                   void* stream);
+
+/* ---- single-kernel entry points (used by the parity tests; same launchers the engine uses) ---------------- */
+int smi_op_gemm(int dtype, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
+                const void* res, const float* lora_xa, const float* lora_up, int lora_r, float lora_scale,
+                int out_f32, void* stream);
+int smi_op_conv3x3(int dtype, const void* in, const void* w_packed, const void* bias, void* out, int nb, int hin,
+                   int win, int cin, int cout, int stride, int upsample, int transposed, int hout, int wout,
+                   void* stream);
+int smi_op_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int b, int h,
+                         int nq, int nk, int d, float scale, void* stream);
+int smi_op_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                         const void* d_o, void* dq, void* dk, void* dv, float* delta, int b, int h, int nq, int nk,
+                         int d, float scale, void* stream);
+int smi_op_groupnorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
+                     float* scratch, int nb, int hw, int c, int g, float eps, int silu, void* stream);
+int smi_op_layernorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
+                     float* mean_rstd, int m, int c, float eps, void* stream);
+int smi_op_geglu(int dtype, const void* proj, void* out, const void* dout, void* dproj, int m, int c4, void* stream);
+int smi_op_lora_down(int dtype, const void* x, const float* a, float* xa, int m, int k, int r, void* stream);
+int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m, int k, int r, float alpha,
+                      float* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMI_H_ */

@@ -81,29 +81,31 @@ def sdxl_config() -> UNetConfig:
 
 
 def tiny_sd1x_config() -> UNetConfig:
-    """Same topology as SD-1.x at 1/10 width (head_dim 8/16/32... kept MFMA-unfriendly on purpose)."""
+    """Same topology as SD-1.x (conv proj_in/out, 4 levels, 1 tf layer) at 1/5 width; head_dim 16/32/64/64.
+    Channel counts stay multiples of 64 (the engine's MFMA K tile) like every real SD channel count."""
     return UNetConfig(
-        block_out_channels=(32, 64, 128, 128),
+        block_out_channels=(64, 128, 256, 256),
         num_attention_heads=(4, 4, 4, 4),
         cross_attention_dim=64,
-        norm_num_groups=8,
+        norm_num_groups=16,
     )
 
 
 def tiny_sdxl_config() -> UNetConfig:
-    """Same topology as SD-XL (linear proj, text_time conditioning, head_dim 16) at 1/10 width, 1/2/3 tf layers."""
+    """Same topology as SD-XL (linear proj, text_time conditioning, no attention at level 0, 1/2/3 tf layers),
+    head_dim 32, at 1/5 width."""
     return UNetConfig(
-        block_out_channels=(32, 64, 128),
+        block_out_channels=(64, 128, 256),
         down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
         up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
         transformer_layers_per_block=(1, 2, 3),
         num_attention_heads=(2, 4, 8),
         cross_attention_dim=64,
-        norm_num_groups=8,
+        norm_num_groups=16,
         use_linear_projection=True,
         addition_embed_type="text_time",
-        addition_time_embed_dim=8,
-        projection_class_embeddings_input_dim=6 * 8 + 32,
+        addition_time_embed_dim=32,
+        projection_class_embeddings_input_dim=6 * 32 + 64,
     )
 
 

@@ -1,0 +1,214 @@
+"""ctypes binding of libsmi_hip.so (include/smi.h).  PyTorch is used only to own device memory and streams:
+tensors are passed as raw device pointers.  There is NO fallback: if the library is missing or fails to load, every
+entry point raises (the product path never computes on the CPU)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmi_hip.so")
+SMI_MAX_LEVELS = 8
+DTYPE_CODE = {torch.float16: 0, torch.bfloat16: 1}
+
+
+class SmiError(RuntimeError):
+    pass
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int), ("n_levels", C.c_int),
+        ("block_out_channels", C.c_int * SMI_MAX_LEVELS), ("down_has_attn", C.c_int * SMI_MAX_LEVELS),
+        ("up_has_attn", C.c_int * SMI_MAX_LEVELS), ("layers_per_block", C.c_int),
+        ("transformer_layers", C.c_int * SMI_MAX_LEVELS), ("num_heads", C.c_int * SMI_MAX_LEVELS),
+        ("mid_transformer_layers", C.c_int), ("cross_attention_dim", C.c_int), ("norm_num_groups", C.c_int),
+        ("use_linear_projection", C.c_int), ("addition_embed", C.c_int), ("addition_time_embed_dim", C.c_int),
+        ("projection_class_embeddings_input_dim", C.c_int),
+    ]
+
+
+class WeightC(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
+
+
+class LoraSiteC(C.Structure):
+    _fields_ = [("target", C.c_char_p), ("off_down", C.c_int64), ("off_up", C.c_int64), ("rank", C.c_int),
+                ("scale", C.c_float)]
+
+
+_lib = None
+
+_SIGS = {
+    "smi_last_error": (C.c_char_p, []),
+    "smi_workspace_bytes": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(LoraSiteC), C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(C.c_size_t)]),
+    "smi_create": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(WeightC), C.c_int, C.POINTER(LoraSiteC), C.c_int,
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                             C.POINTER(C.c_void_p)]),
+    "smi_destroy": (None, [C.c_void_p]),
+    "smi_unet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "smi_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smi_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "smi_slider_loss": (C.c_int, [C.c_void_p] * 4 + [C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]),
+    "smi_clip_adamw": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p,
+                                                                                    C.c_void_p]),
+    "smi_sched_step": (C.c_int, [C.c_void_p] * 3 + [C.c_float] * 3 + [C.c_int64, C.c_void_p]),
+    "smi_op_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "smi_op_conv3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 +
+                       [C.c_void_p]),
+    "smi_op_attention_fwd": (C.c_int, [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "smi_op_attention_bwd": (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "smi_op_groupnorm": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
+    "smi_op_layernorm": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 2 + [C.c_float, C.c_void_p]),
+    "smi_op_geglu": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p]),
+    "smi_op_lora_down": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "smi_op_lora_wgrad": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_void_p,
+                                                                                   C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = sorted(_SIGS)
+
+
+def lib():
+    """Loads the shared library (once).  Raises SmiError if it has not been built -- no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SmiError(f"{LIB_PATH} not found: build it with `python -m sliders_conceptmod_amd.build` "
+                           f"(the HIP extension is mandatory; there is no CPU fallback)")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise SmiError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().smi_last_error()
+        raise SmiError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_config(cfg, dtype: torch.dtype) -> UNetConfigC:
+    """cfg: sliders_conceptmod_amd.unet.UNetConfig (the diffusers public config values)."""
+    c = UNetConfigC()
+    c.dtype = DTYPE_CODE[dtype]
+    c.in_channels = cfg.in_channels
+    c.out_channels = cfg.out_channels
+    n = len(cfg.block_out_channels)
+    c.n_levels = n
+    for i in range(n):
+        c.block_out_channels[i] = cfg.block_out_channels[i]
+        c.down_has_attn[i] = int(cfg.down_block_types[i] == "CrossAttnDownBlock2D")
+        c.up_has_attn[i] = int(cfg.up_block_types[i] == "CrossAttnUpBlock2D")
+        c.transformer_layers[i] = cfg.transformer_layers_per_block[i]
+        c.num_heads[i] = cfg.num_attention_heads[i]
+    c.layers_per_block = cfg.layers_per_block
+    c.mid_transformer_layers = cfg.mid_block_transformer_layers or cfg.transformer_layers_per_block[-1]
+    c.cross_attention_dim = cfg.cross_attention_dim
+    c.norm_num_groups = cfg.norm_num_groups
+    c.use_linear_projection = int(cfg.use_linear_projection)
+    c.addition_embed = int(cfg.addition_embed_type == "text_time")
+    c.addition_time_embed_dim = cfg.addition_time_embed_dim
+    c.projection_class_embeddings_input_dim = cfg.projection_class_embeddings_input_dim
+    return c
+
+
+def make_sites(sites: Sequence[dict]):
+    """sites: [{'target': str, 'off_down': int, 'off_up': int, 'rank': int, 'scale': float}]"""
+    arr = (LoraSiteC * max(1, len(sites)))()
+    keep = []
+    for i, s in enumerate(sites):
+        b = s["target"].encode()
+        keep.append(b)
+        arr[i].target = b
+        arr[i].off_down = s["off_down"]
+        arr[i].off_up = s["off_up"]
+        arr[i].rank = s["rank"]
+        arr[i].scale = s["scale"]
+    return arr, keep
+
+
+def workspace_bytes(cfg_c: UNetConfigC, sites: Sequence[dict], batch: int, h: int, w: int, ctx_len: int) -> int:
+    arr, _keep = make_sites(sites)
+    out = C.c_size_t(0)
+    check(lib().smi_workspace_bytes(C.byref(cfg_c), arr, len(sites), batch, h, w, ctx_len, C.byref(out)),
+          "smi_workspace_bytes")
+    return out.value
+
+
+class Engine:
+    """Owns one smi_engine plus the torch tensors backing its workspace."""
+
+    def __init__(self, cfg, dtype: torch.dtype, state: dict, sites: Sequence[dict], batch: int, h: int, w: int,
+                 ctx_len: int, device):
+        self.cfg_c = make_config(cfg, dtype)
+        self.dtype = dtype
+        self.batch, self.h, self.w, self.ctx_len = batch, h, w, ctx_len
+        self.sites = list(sites)
+        nbytes = workspace_bytes(self.cfg_c, sites, batch, h, w, ctx_len)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._weights_keepalive = []
+        warr = (WeightC * len(state))()
+        names = []
+        for i, (k, v) in enumerate(state.items()):
+            if v.dtype != dtype or not v.is_contiguous() or v.device != self.workspace.device:
+                raise SmiError(f"weight {k}: expected contiguous {dtype} on {self.workspace.device}")
+            nb = k.encode()
+            names.append(nb)
+            warr[i].name = nb
+            warr[i].data = v.data_ptr()
+            warr[i].ndim = v.ndim
+            for d in range(v.ndim):
+                warr[i].shape[d] = v.shape[d]
+            self._weights_keepalive.append(v)
+        sarr, keep = make_sites(sites)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.workspace.device):
+            check(lib().smi_create(C.byref(self.cfg_c), warr, len(state), sarr, len(sites), batch, h, w, ctx_len,
+                                   ptr(self.workspace), nbytes, stream_ptr(), C.byref(handle)), "smi_create")
+        self.handle = handle
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def forward(self, sample: torch.Tensor, timestep: float, ctx: torch.Tensor, text_embeds, time_ids, lora_down,
+                lora_up, multiplier: float, save: bool) -> torch.Tensor:
+        n = sample.shape[0]
+        eps = torch.empty(sample.shape, dtype=torch.float32, device=sample.device)
+        check(lib().smi_unet_forward(self.handle, n, ptr(sample), float(timestep), ptr(ctx), ptr(text_embeds),
+                                     ptr(time_ids), ptr(lora_down), ptr(lora_up), float(multiplier), int(save),
+                                     ptr(eps)), "smi_unet_forward")
+        return eps
+
+    def backward(self, d_eps: torch.Tensor, d_down: torch.Tensor, d_up: torch.Tensor):
+        check(lib().smi_unet_backward(self.handle, ptr(d_eps), ptr(d_down), ptr(d_up)), "smi_unet_backward")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().smi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

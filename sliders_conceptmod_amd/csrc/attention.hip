@@ -1,0 +1,578 @@
+// Fused (flash-style) attention forward + backward for gfx950, non-causal, no mask, head_dim D in {8..160}.
+//
+// MFMA shape: v_mfma_f32_32x32x16_{f16,bf16}.  Scores are produced TRANSPOSED, S^T[key, q] = K . Q^T, so that a
+// lane owns ONE query column (q = lane & 31) and 16 keys per 32x32 tile in its registers: the online-softmax
+// max / sum are register reductions plus a single cross-half exchange, and the f32 accumulator tile, converted
+// pairwise to 16-bit, is already the B operand of the next product (O^T = V^T . P^T) -- no LDS round trip for P
+// (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").  The A operand of that
+// product needs V with the key index contiguous, so V (and K / Q / dO in the backward) is staged into LDS both
+// row-major and transposed.  LDS rows are padded (+16 B / +8 B) so fragment reads are bank-conflict free.
+//
+// Backward (activations only: dQ, and dK/dV when a LoRA hangs off to_k/to_v) recomputes P from Q, K and the
+// forward's log-sum-exp; it is split into a dQ kernel (one workgroup per 128 queries, sweeping keys) and a dK/dV
+// kernel (one workgroup per 128 keys, sweeping queries): no atomics, bitwise reproducible.
+#include "kernels.h"
+
+namespace smi {
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int TK = 64;   // keys (or queries) per staged tile
+constexpr int LDT = 68;  // row length (elements) of transposed tiles [d][64 + 4]
+
+template <typename T, int DP>
+struct Stage {
+  static constexpr int LDN = DP + 8;   // row length of natural tiles [64][DP + 8]
+  static constexpr int NIT = DP / 32;  // 16-byte chunks per thread per tile (64 * DP/8 / 256)
+  static constexpr int CPR = DP / 8;   // chunks per row
+
+  // loads one [64 x D] tile (rows row0.., head columns) into registers
+  static __device__ __forceinline__ void load(u32x4 (&reg)[NIT], __amdgpu_buffer_rsrc_t r, int64_t row0, int nrows,
+                                              int64_t ld, int col0, int D, int tid) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const bool ok = (row0 + row < nrows) && (ch * 8 < D);
+      const uint32_t off = ok ? (uint32_t)(((row0 + row) * ld + col0 + ch * 8) * 2) : OOB;
+      reg[i] = buf_load16(r, off);
+    }
+  }
+  static __device__ __forceinline__ void store_nat(const u32x4 (&reg)[NIT], T* dst, int tid) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      *reinterpret_cast<u32x4*>(dst + row * LDN + ch * 8) = reg[i];
+    }
+  }
+  static __device__ __forceinline__ void store_tr(const u32x4 (&reg)[NIT], T* dst, int tid) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      Pack8<T> t;
+      t.u = reg[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[(ch * 8 + e) * LDT + row] = t.e[e];
+    }
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 pack8(const f32x16& a, int s) {
+  Pack8<T> t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t.e[j] = from_f<T>(a[8 * s + j]);
+  return t.v;
+}
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 ld_frag_nat(const T* tile, int ldn, int row, int col) {
+  Pack8<T> t;
+  t.u = *reinterpret_cast<const u32x4*>(tile + row * ldn + col);
+  return t.v;
+}
+// A-operand fragment from a transposed tile Xt[d][idx]: elements j<4 at idx0 + j, j>=4 at idx0 + 8 + (j-4)
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 ld_frag_tr(const T* tile, int d, int idx0) {
+  Pack8<T> t;
+  const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + d * LDT + idx0);
+  const u32x2 hi = *reinterpret_cast<const u32x2*>(tile + d * LDT + idx0 + 8);
+  t.u = u32x4{lo[0], lo[1], hi[0], hi[1]};
+  return t.v;
+}
+__device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+
+// =============================================================================================================
+// forward
+// =============================================================================================================
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  using S = Stage<T, DP>;
+  constexpr int NS = DP / 16, NB = DP / 32;
+  __shared__ __attribute__((aligned(16))) T Ks[TK * S::LDN];
+  __shared__ __attribute__((aligned(16))) T Vt[DP * LDT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q_idx = blockIdx.x * 128 + wave * 32 + ql;
+  const int col0 = head * p.D;
+  const int nsd = (p.D + 15) / 16;
+
+  const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
+  const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
+  const auto rV = make_rsrc((const T*)p.V + (int64_t)b * p.Nk * p.ldv, (uint32_t)((int64_t)p.Nk * p.ldv * 2));
+
+  typename TT<T>::v8 qf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int d = 16 * s + 8 * h2;
+    const bool ok = (q_idx < p.Nq) && (d < p.D);
+    Pack8<T> t;
+    t.u = buf_load16(rQ, ok ? (uint32_t)(((int64_t)q_idx * p.ldq + col0 + d) * 2) : OOB);
+    qf[s] = t.v;
+  }
+
+  f32x16 o[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_part = 0.f;
+  const float sl = p.scale * LOG2E;
+
+  const int ntiles = (p.Nk + TK - 1) / TK;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * TK;
+    u32x4 rk[S::NIT], rv[S::NIT];
+    S::load(rk, rK, k0, p.Nk, p.ldk, col0, p.D, tid);
+    S::load(rv, rV, k0, p.Nk, p.ldv, col0, p.D, tid);
+    __syncthreads();  // previous tile fully consumed
+    S::store_nat(rk, Ks, tid);
+    S::store_tr(rv, Vt, tid);
+    __syncthreads();
+
+    f32x16 st[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s < nsd) {
+          const auto kf = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
+          st[sub] = TT<T>::mfma32(kf, qf[s], st[sub]);
+        }
+      }
+    }
+    // mask keys beyond Nk, tile max
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + sub * 32 + acc_row(r, h2);
+        if (key >= p.Nk) st[sub][r] = -INFINITY;
+        mloc = fmaxf(mloc, st[sub][r]);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl);
+    m_run = m_new;
+    float psum = 0.f;
+    const float mb = m_new * sl;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(st[sub][r] * sl - mb);
+        st[sub][r] = pv;
+        psum += pv;
+      }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // O^T[d, q] += V^T[d, keys] . P^T[keys, q]
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const auto pf = pack8<T>(st[sub], s2);
+        const int kb = sub * 32 + s2 * 16 + 4 * h2;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const auto vf = ld_frag_tr<T>(Vt, i * 32 + ql, kb);
+          o[i] = TT<T>::mfma32(vf, pf, o[i]);
+        }
+      }
+  }
+
+  const float l_tot = l_part + __shfl_xor(l_part, 32);
+  const float inv = 1.f / l_tot;
+  if (q_idx < p.Nq) {
+    T* orow = (T*)p.O + ((int64_t)b * p.Nq + q_idx) * p.ldo + col0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = i * 32 + 8 * g + 4 * h2;
+        if (d < p.D) {
+          Pack4<T> t;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t.e[j] = from_f<T>(o[i][4 * g + j] * inv);
+          *reinterpret_cast<u32x2*>(orow + d) = t.u;
+        }
+      }
+    if (p.lse && h2 == 0) p.lse[((int64_t)b * p.H + head) * p.Nq + q_idx] = m_run * p.scale + __logf(l_tot);
+  }
+}
+
+// =============================================================================================================
+// backward: delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+// =============================================================================================================
+template <typename T>
+__global__ void attn_delta_kernel(AttnParams p) {
+  const int64_t total = (int64_t)p.B * p.H * p.Nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int h = (int)(i % p.H);
+    const int64_t tok = i / p.H;  // b*Nq + q
+    const T* o = (const T*)p.O + tok * p.ldo + h * p.D;
+    const T* g = (const T*)p.dO + tok * p.lddo + h * p.D;
+    float acc = 0.f;
+    for (int d = 0; d < p.D; d += 8) {
+      Pack8<T> a, c;
+      a.u = *reinterpret_cast<const u32x4*>(o + d);
+      c.u = *reinterpret_cast<const u32x4*>(g + d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += to_f(a.e[j]) * to_f(c.e[j]);
+    }
+    const int64_t bb = tok / p.Nq, q = tok - bb * p.Nq;
+    p.delta[(bb * p.H + h) * p.Nq + q] = acc;
+  }
+}
+
+// =============================================================================================================
+// backward: dQ.  One workgroup = 128 queries (4 waves x 32), sweeping 64-key tiles.
+//   S^T = K Q^T ; P^T = exp(scale*S^T - lse[q]) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta[q])
+//   dQ^T[d,q] += K^T[d,keys] dS^T[keys,q]
+// =============================================================================================================
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  using S = Stage<T, DP>;
+  constexpr int NS = DP / 16, NB = DP / 32;
+  __shared__ __attribute__((aligned(16))) T Ks[TK * S::LDN];
+  __shared__ __attribute__((aligned(16))) T Vs[TK * S::LDN];
+  __shared__ __attribute__((aligned(16))) T Kt[DP * LDT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q_idx = blockIdx.x * 128 + wave * 32 + ql;
+  const int col0 = head * p.D;
+  const int nsd = (p.D + 15) / 16;
+
+  const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
+  const auto rG = make_rsrc((const T*)p.dO + (int64_t)b * p.Nq * p.lddo, (uint32_t)((int64_t)p.Nq * p.lddo * 2));
+  const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
+  const auto rV = make_rsrc((const T*)p.V + (int64_t)b * p.Nk * p.ldv, (uint32_t)((int64_t)p.Nk * p.ldv * 2));
+
+  typename TT<T>::v8 qf[NS], gf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int d = 16 * s + 8 * h2;
+    const bool ok = (q_idx < p.Nq) && (d < p.D);
+    Pack8<T> t, u;
+    t.u = buf_load16(rQ, ok ? (uint32_t)(((int64_t)q_idx * p.ldq + col0 + d) * 2) : OOB);
+    u.u = buf_load16(rG, ok ? (uint32_t)(((int64_t)q_idx * p.lddo + col0 + d) * 2) : OOB);
+    qf[s] = t.v;
+    gf[s] = u.v;
+  }
+  const bool qok = q_idx < p.Nq;
+  const int64_t stat = ((int64_t)b * p.H + head) * p.Nq + (qok ? q_idx : 0);
+  const float lse2 = qok ? p.lse[stat] * LOG2E : INFINITY;
+  const float dlt = qok ? p.delta[stat] : 0.f;
+  const float sl = p.scale * LOG2E;
+
+  f32x16 dq[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  const int ntiles = (p.Nk + TK - 1) / TK;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * TK;
+    u32x4 rk[S::NIT], rv[S::NIT];
+    S::load(rk, rK, k0, p.Nk, p.ldk, col0, p.D, tid);
+    S::load(rv, rV, k0, p.Nk, p.ldv, col0, p.D, tid);
+    __syncthreads();
+    S::store_nat(rk, Ks, tid);
+    S::store_tr(rk, Kt, tid);
+    S::store_nat(rv, Vs, tid);
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = 0.f;
+        dp[r] = 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s < nsd) {
+          const auto kf = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
+          st = TT<T>::mfma32(kf, qf[s], st);
+          const auto vf = ld_frag_nat<T>(Vs, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
+          dp = TT<T>::mfma32(vf, gf[s], dp);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + sub * 32 + acc_row(r, h2);
+        const float pv = (key < p.Nk) ? __builtin_amdgcn_exp2f(st[r] * sl - lse2) : 0.f;
+        st[r] = pv * (dp[r] - dlt);  // dS^T
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const auto df = pack8<T>(st, s2);
+        const int kb = sub * 32 + s2 * 16 + 4 * h2;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const auto kf = ld_frag_tr<T>(Kt, i * 32 + ql, kb);
+          dq[i] = TT<T>::mfma32(kf, df, dq[i]);
+        }
+      }
+    }
+  }
+  if (qok) {
+    T* row = (T*)p.dQ + ((int64_t)b * p.Nq + q_idx) * p.lddq + col0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = i * 32 + 8 * g + 4 * h2;
+        if (d < p.D) {
+          Pack4<T> t;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t.e[j] = from_f<T>(dq[i][4 * g + j] * p.scale);
+          *reinterpret_cast<u32x2*>(row + d) = t.u;
+        }
+      }
+  }
+}
+
+// =============================================================================================================
+// backward: dK, dV.  One workgroup = 128 keys (4 waves x 32, key on the lane), sweeping 64-query tiles.
+//   S[q,key] = Q K^T ; P = exp(scale*S - lse[q]) ; dP[q,key] = dO V^T ; dS = P o (dP - delta[q])
+//   dV^T[d,key] += dO^T[d,q] P[q,key] ;  dK^T[d,key] += Q^T[d,q] dS[q,key]
+// WHICH: 1 = dK only, 2 = dV only, 3 = both (register budget: both only fits for DP <= 96)
+// =============================================================================================================
+template <typename T, int DP, int WHICH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+  using S = Stage<T, DP>;
+  constexpr int NS = DP / 16, NB = DP / 32;
+  constexpr bool DO_DK = (WHICH & 1) != 0, DO_DV = (WHICH & 2) != 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  T* Qs = reinterpret_cast<T*>(dyn_smem);
+  T* Gs = Qs + TK * S::LDN;
+  T* Qt = Gs + TK * S::LDN;
+  T* Gt = Qt + DP * LDT;
+  float* lse_s = reinterpret_cast<float*>(Gt + DP * LDT);
+  float* dlt_s = lse_s + TK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kl = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int k_idx = blockIdx.x * 128 + wave * 32 + kl;
+  const int col0 = head * p.D;
+  const int nsd = (p.D + 15) / 16;
+
+  const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
+  const auto rG = make_rsrc((const T*)p.dO + (int64_t)b * p.Nq * p.lddo, (uint32_t)((int64_t)p.Nq * p.lddo * 2));
+  const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
+  const auto rV = make_rsrc((const T*)p.V + (int64_t)b * p.Nk * p.ldv, (uint32_t)((int64_t)p.Nk * p.ldv * 2));
+
+  typename TT<T>::v8 kf[NS], vf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int d = 16 * s + 8 * h2;
+    const bool ok = (k_idx < p.Nk) && (d < p.D);
+    Pack8<T> t, u;
+    t.u = buf_load16(rK, ok ? (uint32_t)(((int64_t)k_idx * p.ldk + col0 + d) * 2) : OOB);
+    u.u = buf_load16(rV, ok ? (uint32_t)(((int64_t)k_idx * p.ldv + col0 + d) * 2) : OOB);
+    kf[s] = t.v;
+    vf[s] = u.v;
+  }
+  const float sl = p.scale * LOG2E;
+  const int64_t stat0 = ((int64_t)b * p.H + head) * p.Nq;
+
+  f32x16 dk[DO_DK ? NB : 1], dv[DO_DV ? NB : 1];
+#pragma unroll
+  for (int i = 0; i < (DO_DK ? NB : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (DO_DV ? NB : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[i][r] = 0.f;
+
+  const int ntiles = (p.Nq + TK - 1) / TK;
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int q0 = qt * TK;
+    u32x4 rq[S::NIT], rg[S::NIT];
+    S::load(rq, rQ, q0, p.Nq, p.ldq, col0, p.D, tid);
+    S::load(rg, rG, q0, p.Nq, p.lddo, col0, p.D, tid);
+    float lv = 0.f, dl = 0.f;
+    if (tid < TK) {
+      const bool ok = q0 + tid < p.Nq;
+      lv = ok ? p.lse[stat0 + q0 + tid] * LOG2E : INFINITY;  // +inf -> P = 0 for padded queries
+      dl = ok ? p.delta[stat0 + q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    S::store_nat(rq, Qs, tid);
+    S::store_nat(rg, Gs, tid);
+    if (DO_DK) S::store_tr(rq, Qt, tid);
+    if (DO_DV) S::store_tr(rg, Gt, tid);
+    if (tid < TK) {
+      lse_s[tid] = lv;
+      dlt_s[tid] = dl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = 0.f;
+        dp[r] = 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s < nsd) {
+          const auto qa = ld_frag_nat<T>(Qs, S::LDN, sub * 32 + kl, 16 * s + 8 * h2);
+          st = TT<T>::mfma32(qa, kf[s], st);
+          if (DO_DK) {
+            const auto ga = ld_frag_nat<T>(Gs, S::LDN, sub * 32 + kl, 16 * s + 8 * h2);
+            dp = TT<T>::mfma32(ga, vf[s], dp);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = sub * 32 + acc_row(r, h2);
+        const float pv = __builtin_amdgcn_exp2f(st[r] * sl - lse_s[qi]);
+        st[r] = pv;
+        if (DO_DK) dp[r] = pv * (dp[r] - dlt_s[qi]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int qb = sub * 32 + s2 * 16 + 4 * h2;
+        if (DO_DV) {
+          const auto pf = pack8<T>(st, s2);
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            const auto ga = ld_frag_tr<T>(Gt, i * 32 + kl, qb);
+            dv[i] = TT<T>::mfma32(ga, pf, dv[i]);
+          }
+        }
+        if (DO_DK) {
+          const auto df = pack8<T>(dp, s2);
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            const auto qa = ld_frag_tr<T>(Qt, i * 32 + kl, qb);
+            dk[i] = TT<T>::mfma32(qa, df, dk[i]);
+          }
+        }
+      }
+    }
+  }
+  if (k_idx < p.Nk) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = i * 32 + 8 * g + 4 * h2;
+        if (d < p.D) {
+          if (DO_DK) {
+            Pack4<T> t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t.e[j] = from_f<T>(dk[i][4 * g + j] * p.scale);
+            *reinterpret_cast<u32x2*>((T*)p.dK + ((int64_t)b * p.Nk + k_idx) * p.lddk + col0 + d) = t.u;
+          }
+          if (DO_DV) {
+            Pack4<T> t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t.e[j] = from_f<T>(dv[i][4 * g + j]);
+            *reinterpret_cast<u32x2*>((T*)p.dV + ((int64_t)b * p.Nk + k_idx) * p.lddv + col0 + d) = t.u;
+          }
+        }
+      }
+  }
+}
+
+template <typename T, int DP>
+size_t dkv_smem() {
+  return (size_t)(2 * TK * Stage<T, DP>::LDN + 2 * DP * LDT) * sizeof(T) + 2 * TK * sizeof(float);
+}
+
+int check_attn(const AttnParams& p) {
+  SMI_CHECK(p.D % 8 == 0 && p.D >= 8 && p.D <= 160, "attention: head_dim %d unsupported (need D %% 8 == 0, <= 160)", p.D);
+  SMI_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must be 16-byte multiples");
+  SMI_CHECK(p.B > 0 && p.H > 0 && p.Nq > 0 && p.Nk > 0, "attention: empty shape");
+  SMI_CHECK((int64_t)p.Nq * p.ldq * 2 < 0xFFFFFFF0ll && (int64_t)p.Nk * p.ldk * 2 < 0xFFFFFFF0ll, "attention: per-batch tensor larger than 4 GiB");
+  return 0;
+}
+
+template <typename T, int DP>
+int fwd_t(const AttnParams& p, hipStream_t st) {
+  dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DP>), grid, dim3(256), 0, st, p);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int DP>
+int bwd_t(const AttnParams& p, hipStream_t st) {
+  {
+    const int64_t total = (int64_t)p.B * p.H * p.Nq;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, st, p);
+  }
+  if (p.dQ) {
+    dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP>), grid, dim3(256), 0, st, p);
+  }
+  if (p.dK || p.dV) {
+    SMI_CHECK(p.dK && p.dV, "attention bwd: dK and dV must both be given");
+    dim3 grid(cdiv(p.Nk, 128), p.H, p.B);
+    const size_t sm = dkv_smem<T, DP>();
+    if (DP <= 96) {
+      static bool attr_set = false;
+      if (!attr_set && sm > 65536) {
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 3>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 3>), grid, dim3(256), sm, st, p);
+    } else {
+      static bool attr_set = false;
+      if (!attr_set) {
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 1>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 2>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 1>), grid, dim3(256), sm, st, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 2>), grid, dim3(256), sm, st, p);
+    }
+  }
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int dispatch(const AttnParams& p, hipStream_t st, bool bwd) {
+  if (p.D <= 32) return bwd ? bwd_t<T, 32>(p, st) : fwd_t<T, 32>(p, st);
+  if (p.D <= 64) return bwd ? bwd_t<T, 64>(p, st) : fwd_t<T, 64>(p, st);
+  if (p.D <= 96) return bwd ? bwd_t<T, 96>(p, st) : fwd_t<T, 96>(p, st);
+  return bwd ? bwd_t<T, 160>(p, st) : fwd_t<T, 160>(p, st);
+}
+
+}  // namespace
+
+int launch_attn_fwd(const AttnParams& p, hipStream_t stream) {
+  if (check_attn(p)) return -1;
+  return p.dtype == DT_F16 ? dispatch<f16>(p, stream, false) : dispatch<bf16>(p, stream, false);
+}
+int launch_attn_bwd(const AttnParams& p, hipStream_t stream) {
+  if (check_attn(p)) return -1;
+  SMI_CHECK(p.lse && p.delta && p.dO && p.O, "attention bwd: lse/delta/dO/O required");
+  return p.dtype == DT_F16 ? dispatch<f16>(p, stream, true) : dispatch<bf16>(p, stream, true);
+}
+
+}  // namespace smi

@@ -1,0 +1,1359 @@
+// UNet2DCondition engine: executes the SD-1.x / SD-XL denoising forward and the activation/LoRA-gradient backward
+// as a stream of hand-written gfx950 kernels (gemm.hip, attention.hip, norm.hip, elementwise.hip, lora.hip).
+//
+// Structure
+//   * Activations are token-major [n*H*W, C] in the model dtype (fp16/bf16); accumulation is fp32 everywhere.
+//   * Frozen weights are borrowed from the caller in torch layout ([out, in] is already the K-contiguous "NT" operand)
+//     and complemented at creation by packed copies inside the workspace: transposed matrices for the dX GEMMs,
+//     (ky,kx,ci)-ordered conv filters (+ flipped/transposed gradient filters), fused q|k|v and k|v projections.
+//   * Memory: two bump arenas sized by a dry run of the same code (no reuse inside a pass -- 288 GB of HBM makes
+//     that the simple and fast choice): arena 0 serves no-grad passes, arena 1 the pass that is differentiated and
+//     its backward, so a frozen pass can never clobber saved activations.
+//   * Autograd: every op pushes a closure on a tape when its output depends on an adapted layer; the backward pops
+//     them in reverse.  Gradients exist only downstream of the first adapted layer; frozen weights get none.
+//     Residual / skip fan-in is accumulated inside the producing kernel (GEMM `res` epilogue, norm `add` operand).
+//   * 16-bit gradient range: d_eps is multiplied by a power-of-two loss scale chosen on the device from max|d_eps|;
+//     the LoRA weight-gradient kernels divide it out (they accumulate in fp32).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <deque>
+
+#include "../../include/smi.h"
+#include "kernels.h"
+
+namespace smi {
+
+static thread_local char g_err[2048] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int launch_nchw_to_nhwc_scaled(int dtype, const float* src, void* dst, int Nb, int C, int HW, int Cpad,
+                               const float* scale_dev, hipStream_t stream);
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// weight packing kernels (run once at creation)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int C, int ldd,
+                                      int col0) {
+  // dst[c][col0 + r] = src[r][c]
+  const int64_t total = (int64_t)R * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    dst[(int64_t)c * ldd + col0 + r] = src[i];
+  }
+}
+// conv weight [Cout, Cin, 3, 3] -> forward pack  dst[co][(ky*3+kx)*Cin + ci]
+//                               -> gradient pack dst[ci][(ty*3+tx)*Cout + co] = w[co][ci][ky][kx],
+//                                  (ty,tx) = flip ? (2-ky, 2-kx) : (ky, kx)
+template <typename T>
+__global__ void pack_conv_kernel(const T* __restrict__ src, T* __restrict__ dst, int Cout, int Cin, int mode) {
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % 9);
+    const int ci = (int)((i / 9) % Cin);
+    const int co = (int)(i / (9 * (int64_t)Cin));
+    const int ky = t / 3, kx = t % 3;
+    if (mode == 0) {
+      dst[((int64_t)co * 9 + t) * Cin + ci] = src[i];
+    } else {
+      const int tt = mode == 2 ? (2 - ky) * 3 + (2 - kx) : t;
+      dst[((int64_t)ci * 9 + tt) * Cout + co] = src[i];
+    }
+  }
+}
+__global__ void fill_kernel(float* p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool overflow = false;
+  void reset() { off = 0; }
+  void* alloc(size_t bytes) {
+    off = align_up(off, 256);
+    void* p = base + off;
+    off += bytes;
+    if (off > peak) peak = off;
+    if (off > cap) overflow = true;
+    return p;
+  }
+};
+
+struct Ten {
+  void* p = nullptr;
+  void* g = nullptr;
+  int64_t rows = 0;
+  int cols = 0;
+  int n = 0, H = 0, W = 0;  // rows = n*H*W for image tensors
+  bool ng = false;
+};
+
+struct Lin {
+  std::string name;
+  const void* W = nullptr;   // [out, in]
+  const void* Wt = nullptr;  // [in, out]
+  const void* b = nullptr;
+  int in = 0, out = 0;
+  // LoRA (fused projections carry nseg adjacent sites)
+  int nseg = 1;
+  int nsite = 0;
+  int rank = 0;
+  float scale = 0.f;
+  int64_t off_down = 0, off_up = 0;
+};
+struct Conv {
+  const void* Wp = nullptr;   // forward pack [Cout][9*Cin]
+  const void* Wg = nullptr;   // gradient pack [Cin][9*Cout]
+  const void* b = nullptr;
+  int Cin = 0, Cout = 0;
+  int mode = 0;  // 0 stride 1, 1 stride-2 downsample, 2 nearest-2x upsample + conv
+};
+struct Norm {
+  const void* gamma = nullptr;
+  const void* beta = nullptr;
+  int C = 0;
+  float eps = 1e-5f;
+};
+struct Resnet {
+  Norm n1, n2;
+  Conv c1, c2;
+  Lin temb, sc;
+  bool has_sc = false;
+};
+struct TBlock {
+  Norm n1, n2, n3;
+  Lin qkv1, out1, q2, kv2, out2, ff1, ff2;
+};
+struct Transformer {
+  Norm norm;
+  Lin proj_in, proj_out;
+  std::vector<TBlock> blocks;
+  int heads = 0, C = 0;
+};
+struct Level {
+  std::vector<Resnet> res;
+  std::vector<Transformer> att;
+  bool has_att = false;
+  bool has_samp = false;
+  Conv samp;
+};
+
+}  // namespace
+}  // namespace smi
+
+using namespace smi;
+
+struct smi_engine {
+  smi_unet_config cfg{};
+  int dtype = 0;
+  hipStream_t stream = nullptr;
+  bool dry = false;
+  bool err = false;
+  int max_n = 0, lat_h = 0, lat_w = 0, ctx_len = 0;
+
+  // workspace layout
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  Arena wpack;     // packed weights + persistent small buffers
+  Arena arena[2];  // 0: no-grad passes, 1: differentiated pass + backward
+  Arena* cur = nullptr;
+  float* gscale = nullptr;  // [0]=scale [1]=1/scale [2..258) scratch
+
+  std::unordered_map<std::string, const smi_weight*> wmap;
+  std::unordered_map<std::string, const smi_lora_site*> smap;
+  std::vector<smi_lora_site> sites;
+  std::vector<std::string> site_names;
+  std::vector<char> site_used;
+
+  // model
+  Conv conv_in, conv_out;
+  Norm norm_out;
+  Lin time1, time2, add1, add2;
+  std::vector<Level> down, up;
+  Level mid;
+
+  // per-call state
+  std::deque<Ten> tens_[2];  // per arena: a no-grad pass must not invalidate the tensors the tape refers to
+  std::deque<Ten>* tens = &tens_[0];
+  std::vector<std::function<void()>> tape;
+  bool saving = false;
+  bool tape_valid = false;
+  const float* lora_down = nullptr;  // parameters of the forward in flight
+  const float* lora_up = nullptr;
+  const float* bw_down = nullptr;    // parameters of the saved (differentiated) forward, used by its backward
+  const float* bw_up = nullptr;
+  float mult = 0.f;
+  float* d_down = nullptr;
+  float* d_up = nullptr;
+  Ten* out_ten = nullptr;  // conv_out result (f32 [rows, 4])
+  int last_n = 0;
+
+  size_t esz() const { return 2; }
+
+  // ---------------------------------------------------------------------------------------------------------
+  void fail(const char* what) {
+    if (!err) set_error("%s: %s", what, g_err);
+    err = true;
+  }
+#define RUN(call)                          \
+  do {                                     \
+    if (!dry && !err) {                    \
+      if ((call) != 0) {                   \
+        err = true;                        \
+      }                                    \
+    }                                      \
+  } while (0)
+
+  Ten* new_ten(int64_t rows, int cols, int n = 0, int H = 0, int W = 0, size_t elt = 0) {
+    tens->emplace_back();
+    Ten* t = &tens->back();
+    t->rows = rows;
+    t->cols = cols;
+    t->n = n;
+    t->H = H;
+    t->W = W;
+    t->p = arena_alloc((size_t)rows * cols * (elt ? elt : esz()));
+    return t;
+  }
+  void* arena_alloc(size_t bytes) {
+    void* p = cur->alloc(bytes);
+    if (!dry && cur->overflow && !err) {  // never launch a kernel on memory we do not own
+      set_error("workspace arena overflow (%zu > %zu bytes)", cur->off, cur->cap);
+      err = true;
+    }
+    return p;
+  }
+  float* alloc_f32(size_t count) { return (float*)arena_alloc(count * sizeof(float)); }
+  void* alloc_t(int64_t rows, int cols) { return arena_alloc((size_t)rows * cols * esz()); }
+
+  // gradient slot of t: returns buffer to write; `had` tells whether a gradient is already accumulated there
+  void* grad_slot(Ten* t, bool& had) {
+    had = t->g != nullptr;
+    if (!had) t->g = alloc_t(t->rows, t->cols);
+    return t->g;
+  }
+  void accumulate(Ten* t, void* g) {
+    if (!t->g) {
+      t->g = g;  // alias: g is dead after its producer's closure
+    } else {
+      RUN(launch_add(dtype, t->g, g, t->g, t->rows * t->cols, stream));
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------------------------
+  // model construction
+  // ---------------------------------------------------------------------------------------------------------
+  const smi_weight* W(const std::string& name, bool required = true) {
+    auto it = wmap.find(name);
+    if (it == wmap.end()) {
+      if (required && !dry) {
+        set_error("missing weight '%s'", name.c_str());
+        err = true;
+      }
+      return nullptr;
+    }
+    return it->second;
+  }
+  const void* Wd(const std::string& name, bool required = true) {
+    const smi_weight* w = W(name, required);
+    return w ? w->data : nullptr;
+  }
+  void check_shape(const std::string& name, std::initializer_list<int64_t> shp) {
+    if (dry) return;
+    const smi_weight* w = W(name);
+    if (!w) return;
+    int64_t want = 1, have = 1;
+    for (auto v : shp) want *= v;
+    for (int i = 0; i < w->ndim; ++i) have *= w->shape[i];
+    if (want != have) {
+      set_error("weight '%s': expected %lld elements, got %lld", name.c_str(), (long long)want, (long long)have);
+      err = true;
+    }
+  }
+  void* pack_alloc(size_t bytes) { return wpack.alloc(bytes); }
+
+  void transpose_into(const void* src, void* dst, int R, int C, int ldd, int col0) {
+    if (dry || err || !src) return;
+    const int64_t total = (int64_t)R * C;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    if (dtype == DT_F16)
+      hipLaunchKernelGGL(pack_transpose_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, R, C, ldd, col0);
+    else
+      hipLaunchKernelGGL(pack_transpose_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, R, C, ldd, col0);
+  }
+  void pack_conv_into(const void* src, void* dst, int Cout, int Cin, int mode) {
+    if (dry || err || !src) return;
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    if (dtype == DT_F16)
+      hipLaunchKernelGGL(pack_conv_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, Cout, Cin, mode);
+    else
+      hipLaunchKernelGGL(pack_conv_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, Cout, Cin, mode);
+  }
+
+  void attach_lora(Lin& L, const std::vector<std::string>& targets) {
+    // targets: the module paths fused into this GEMM (1, 2 (k|v) or 3 (q|k|v)); all adapted or none
+    int found = 0;
+    const smi_lora_site* first = nullptr;
+    for (size_t i = 0; i < targets.size(); ++i) {
+      auto it = smap.find(targets[i]);
+      if (it == smap.end()) continue;
+      ++found;
+      const smi_lora_site* s = it->second;
+      site_used[s - sites.data()] = 1;
+      if (!first) first = s;
+      if (i > 0 && found == (int)i + 1) {
+        const int cs = L.out / (int)targets.size();
+        if (s->rank != first->rank || s->scale != first->scale ||
+            s->off_down != first->off_down + (int64_t)i * first->rank * L.in ||
+            s->off_up != first->off_up + (int64_t)i * cs * first->rank) {
+          set_error("LoRA sites fused into '%s' must be adjacent in the flat buffers with equal rank/scale",
+                    L.name.c_str());
+          err = true;
+        }
+      }
+    }
+    if (found == 0) return;
+    if (found != (int)targets.size()) {
+      set_error("LoRA must adapt all or none of the projections fused into '%s'", L.name.c_str());
+      err = true;
+      return;
+    }
+    L.nsite = found;
+    L.rank = first->rank;
+    L.scale = first->scale;
+    L.off_down = first->off_down;
+    L.off_up = first->off_up;
+  }
+
+  // need_t: the layer lies on the gradient path (gets a transposed copy) and may carry a LoRA adaptor
+  Lin make_lin(const std::string& name, int in, int out, bool bias, bool need_t = true) {
+    Lin L;
+    L.name = name;
+    L.in = in;
+    L.out = out;
+    L.W = Wd(name + ".weight");
+    check_shape(name + ".weight", {out, in});
+    L.b = bias ? Wd(name + ".bias") : nullptr;
+    if (need_t) {
+      void* t = pack_alloc((size_t)in * out * esz());
+      transpose_into(L.W, t, out, in, out, 0);
+      L.Wt = t;
+      attach_lora(L, {name});
+    }
+    return L;
+  }
+  // fused projection: rows of the parts concatenated ([sum out, in]); Wt [in, sum out]
+  Lin make_fused(const std::string& base, const std::vector<std::string>& parts, int in, int out_each, bool need_t) {
+    Lin L;
+    L.name = base + ".{" + parts[0] + "..}";
+    L.in = in;
+    L.out = out_each * (int)parts.size();
+    L.nseg = (int)parts.size();
+    char* w = (char*)pack_alloc((size_t)L.out * in * esz());
+    char* t = need_t ? (char*)pack_alloc((size_t)L.out * in * esz()) : nullptr;
+    std::vector<std::string> targets;
+    for (size_t i = 0; i < parts.size(); ++i) {
+      const std::string nm = base + "." + parts[i];
+      const void* src = Wd(nm + ".weight");
+      check_shape(nm + ".weight", {out_each, in});
+      if (!dry && !err && src)
+        (void)hipMemcpyAsync(w + i * (size_t)out_each * in * esz(), src, (size_t)out_each * in * esz(),
+                             hipMemcpyDeviceToDevice, stream);
+      if (t) transpose_into(src, t, out_each, in, L.out, (int)i * out_each);
+      targets.push_back(nm);
+    }
+    L.W = w;
+    L.Wt = t;
+    attach_lora(L, targets);
+    return L;
+  }
+  Conv make_conv(const std::string& name, int Cin, int Cout, int mode, bool grad_pack) {
+    Conv c;
+    c.Cin = Cin;
+    c.Cout = Cout;
+    c.mode = mode;
+    c.b = Wd(name + ".bias");
+    check_shape(name + ".weight", {Cout, Cin, 3, 3});
+    void* wp = pack_alloc((size_t)Cout * Cin * 9 * esz());
+    pack_conv_into(Wd(name + ".weight"), wp, Cout, Cin, 0);
+    c.Wp = wp;
+    if (grad_pack) {
+      void* wg = pack_alloc((size_t)Cout * Cin * 9 * esz());
+      pack_conv_into(Wd(name + ".weight"), wg, Cout, Cin, mode == 1 ? 1 : 2);
+      c.Wg = wg;
+    }
+    return c;
+  }
+  Norm make_norm(const std::string& name, int C, float eps) {
+    Norm n;
+    n.C = C;
+    n.eps = eps;
+    n.gamma = Wd(name + ".weight");
+    n.beta = Wd(name + ".bias");
+    check_shape(name + ".weight", {C});
+    return n;
+  }
+  Resnet make_resnet(const std::string& name, int Cin, int Cout) {
+    Resnet r;
+    const int ted = cfg.block_out_channels[0] * 4;
+    r.n1 = make_norm(name + ".norm1", Cin, 1e-5f);
+    r.c1 = make_conv(name + ".conv1", Cin, Cout, 0, true);
+    r.temb = make_lin(name + ".time_emb_proj", ted, Cout, true, false);
+    r.n2 = make_norm(name + ".norm2", Cout, 1e-5f);
+    r.c2 = make_conv(name + ".conv2", Cout, Cout, 0, true);
+    r.has_sc = Cin != Cout;
+    if (r.has_sc) r.sc = make_lin(name + ".conv_shortcut", Cin, Cout, true, true);
+    return r;
+  }
+  Transformer make_transformer(const std::string& name, int C, int heads, int layers) {
+    Transformer t;
+    t.C = C;
+    t.heads = heads;
+    t.norm = make_norm(name + ".norm", C, 1e-6f);
+    t.proj_in = make_lin(name + ".proj_in", C, C, true);
+    for (int k = 0; k < layers; ++k) {
+      const std::string b = name + ".transformer_blocks." + std::to_string(k);
+      TBlock tb;
+      tb.n1 = make_norm(b + ".norm1", C, 1e-5f);
+      tb.qkv1 = make_fused(b + ".attn1", {"to_q", "to_k", "to_v"}, C, C, true);
+      tb.out1 = make_lin(b + ".attn1.to_out.0", C, C, true);
+      tb.n2 = make_norm(b + ".norm2", C, 1e-5f);
+      tb.q2 = make_lin(b + ".attn2.to_q", C, C, false);
+      tb.kv2 = make_fused(b + ".attn2", {"to_k", "to_v"}, cfg.cross_attention_dim, C, false);
+      tb.out2 = make_lin(b + ".attn2.to_out.0", C, C, true);
+      tb.n3 = make_norm(b + ".norm3", C, 1e-5f);
+      tb.ff1 = make_lin(b + ".ff.net.0.proj", C, 8 * C, true);
+      tb.ff2 = make_lin(b + ".ff.net.2", 4 * C, C, true);
+      t.blocks.push_back(tb);
+    }
+    t.proj_out = make_lin(name + ".proj_out", C, C, true);
+    return t;
+  }
+
+  void build() {
+    const int L = cfg.n_levels;
+    const int* boc = cfg.block_out_channels;
+    const int ted = boc[0] * 4;
+    // conv_in: direct small-Cin kernel, weights (ky,kx,ci)-ordered
+    conv_in = make_conv("conv_in", cfg.in_channels, boc[0], 0, false);
+    time1 = make_lin("time_embedding.linear_1", boc[0], ted, true, false);
+    time2 = make_lin("time_embedding.linear_2", ted, ted, true, false);
+    if (cfg.addition_embed) {
+      add1 = make_lin("add_embedding.linear_1", cfg.projection_class_embeddings_input_dim, ted, true, false);
+      add2 = make_lin("add_embedding.linear_2", ted, ted, true, false);
+    }
+    int out_ch = boc[0];
+    down.resize(L);
+    for (int i = 0; i < L; ++i) {
+      const int in_ch = out_ch;
+      out_ch = boc[i];
+      Level& lv = down[i];
+      lv.has_att = cfg.down_has_attn[i] != 0;
+      const std::string b = "down_blocks." + std::to_string(i);
+      for (int j = 0; j < cfg.layers_per_block; ++j) {
+        lv.res.push_back(make_resnet(b + ".resnets." + std::to_string(j), j == 0 ? in_ch : out_ch, out_ch));
+        if (lv.has_att)
+          lv.att.push_back(make_transformer(b + ".attentions." + std::to_string(j), out_ch, cfg.num_heads[i],
+                                            cfg.transformer_layers[i]));
+      }
+      lv.has_samp = i != L - 1;
+      if (lv.has_samp) lv.samp = make_conv(b + ".downsamplers.0.conv", out_ch, out_ch, 1, true);
+    }
+    {
+      const int ch = boc[L - 1];
+      mid.res.push_back(make_resnet("mid_block.resnets.0", ch, ch));
+      mid.att.push_back(make_transformer("mid_block.attentions.0", ch, cfg.num_heads[L - 1],
+                                         cfg.mid_transformer_layers));
+      mid.res.push_back(make_resnet("mid_block.resnets.1", ch, ch));
+    }
+    up.resize(L);
+    out_ch = boc[L - 1];
+    for (int i = 0; i < L; ++i) {
+      const int prev = out_ch;
+      out_ch = boc[L - 1 - i];
+      const int in_ch = boc[L - 1 - std::min(i + 1, L - 1)];
+      Level& lv = up[i];
+      lv.has_att = cfg.up_has_attn[i] != 0;
+      const std::string b = "up_blocks." + std::to_string(i);
+      const int nl = cfg.layers_per_block + 1;
+      for (int j = 0; j < nl; ++j) {
+        const int skip = j == nl - 1 ? in_ch : out_ch;
+        const int rin = j == 0 ? prev : out_ch;
+        lv.res.push_back(make_resnet(b + ".resnets." + std::to_string(j), rin + skip, out_ch));
+        if (lv.has_att)
+          lv.att.push_back(make_transformer(b + ".attentions." + std::to_string(j), out_ch,
+                                            cfg.num_heads[L - 1 - i], cfg.transformer_layers[L - 1 - i]));
+      }
+      lv.has_samp = i != L - 1;
+      if (lv.has_samp) lv.samp = make_conv(b + ".upsamplers.0.conv", out_ch, out_ch, 2, true);
+    }
+    norm_out = make_norm("conv_norm_out", boc[0], 1e-5f);
+    conv_out = make_conv("conv_out", boc[0], cfg.out_channels, 0, false);
+    {  // conv_out gradient filter for the direct small-channel kernel: [C0][9*out_channels], flipped taps
+      void* wg = pack_alloc((size_t)boc[0] * cfg.out_channels * 9 * esz());
+      pack_conv_into(Wd("conv_out.weight"), wg, cfg.out_channels, boc[0], 2);
+      conv_out.Wg = wg;
+    }
+    gscale = (float*)pack_alloc(260 * sizeof(float));
+    for (size_t i = 0; i < sites.size(); ++i)
+      if (!site_used[i] && !err) {
+        set_error("LoRA target '%s' is not an attention projection this engine adapts (lierla/attention-only)",
+                  site_names[i].c_str());
+        err = true;
+      }
+  }
+
+  // ---------------------------------------------------------------------------------------------------------
+  // ops
+  // ---------------------------------------------------------------------------------------------------------
+  bool lora_active(const Lin& L) const { return L.nsite > 0 && (dry || (lora_down && lora_up && mult != 0.f)); }
+
+  Ten* linear(Ten* x, const Lin& L, Ten* res = nullptr) {
+    Ten* y = new_ten(x->rows, L.out, x->n, x->H, x->W);
+    const bool lon = lora_active(L);
+    const int rtot = L.rank * L.nseg;
+    float* xa = nullptr;
+    const float lscale = mult * L.scale;
+    if (lon) {
+      xa = alloc_f32((size_t)x->rows * rtot);
+      RUN(launch_lora_down(dtype, x->p, x->cols, lora_down + L.off_down, L.in, 1, xa, rtot, (int)x->rows, L.in, rtot,
+                           stream));
+    }
+    GemmParams p;
+    p.dtype = dtype;
+    p.A = x->p;
+    p.lda = x->cols;
+    p.W = L.W;
+    p.C = y->p;
+    p.ldc = L.out;
+    p.M = (int)x->rows;
+    p.N = L.out;
+    p.K = L.in;
+    p.bias = L.b;
+    if (res) {
+      p.res = res->p;
+      p.ldr = res->cols;
+    }
+    if (lon) {
+      p.lora_xa = xa;
+      p.ld_xa = rtot;
+      p.lora_up = lora_up + L.off_up;
+      p.up_sn = L.rank;
+      p.up_sq = 1;
+      p.lora_r = L.rank;
+      p.lora_seg = L.nseg > 1 ? L.out / L.nseg : 0;
+      p.lora_scale = lscale;
+    }
+    RUN(launch_gemm(p, stream));
+    y->ng = lon || x->ng || (res && res->ng);
+    if (saving && y->ng) {
+      const Lin* Lp = &L;
+      tape.push_back([=]() { linear_bwd(x, Lp, res, y, xa, lon, lscale); });
+    }
+    return y;
+  }
+  void linear_bwd(Ten* x, const Lin* L, Ten* res, Ten* y, float* xa, bool lon, float lscale) {
+    void* dy = y->g;
+    if (!dy) return;
+    if (res && res->ng) accumulate(res, dy);
+    const int M = (int)x->rows;
+    const int rtot = L->rank * L->nseg;
+    float* dxa = nullptr;
+    if (lon) {
+      const int cs = L->out / L->nseg;
+      const int r = L->rank;
+      dxa = alloc_f32((size_t)M * rtot);
+      float* scratch = alloc_f32(std::max(lora_wgrad_scratch_floats(M, cs, r), lora_wgrad_scratch_floats(M, L->in, r)));
+      for (int s = 0; s < L->nseg; ++s) {
+        const char* dys = (const char*)dy + (size_t)s * cs * esz();
+        // d(up_s)[n][q] += lscale/S * sum_m dy[m][s*cs+n] * xa[m][s*r+q]
+        RUN(launch_lora_wgrad(dtype, xa + s * r, rtot, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
+                              cs, r, lscale, gscale + 1, scratch, stream));
+        // dxa_s[m][q] = sum_n dy[m][s*cs+n] * up_s[n][q]
+        RUN(launch_lora_down(dtype, dys, L->out, bw_up + L->off_up + (int64_t)s * cs * r, 1, r, dxa + s * r, rtot,
+                             M, cs, r, stream));
+      }
+      for (int s = 0; s < L->nseg; ++s) {
+        // d(down_s)[q][k] += lscale/S * sum_m dxa[m][s*r+q] * x[m][k]
+        RUN(launch_lora_wgrad(dtype, dxa + s * r, rtot, x->p, x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
+                              L->in, 1, M, L->in, r, lscale, gscale + 1, scratch, stream));
+      }
+    }
+    if (x->ng) {
+      if (!L->Wt && !dry) {
+        set_error("internal: no transposed weight for '%s'", L->name.c_str());
+        err = true;
+        return;
+      }
+      bool had;
+      void* dx = grad_slot(x, had);
+      GemmParams p;
+      p.dtype = dtype;
+      p.A = dy;
+      p.lda = L->out;
+      p.W = L->Wt;
+      p.C = dx;
+      p.ldc = L->in;
+      p.M = M;
+      p.N = L->in;
+      p.K = L->out;
+      if (had) {
+        p.res = dx;
+        p.ldr = L->in;
+      }
+      if (lon) {
+        p.lora_xa = dxa;
+        p.ld_xa = rtot;
+        p.lora_up = bw_down + L->off_down;  // A_cat [rtot, in] read as [in][rtot]
+        p.up_sn = 1;
+        p.up_sq = L->in;
+        p.lora_r = rtot;
+        p.lora_seg = 0;
+        p.lora_scale = lscale;
+      }
+      RUN(launch_gemm(p, stream));
+    }
+  }
+
+  Ten* layernorm(Ten* x, const Norm& nm) {
+    Ten* y = new_ten(x->rows, x->cols, x->n, x->H, x->W);
+    float* st = alloc_f32((size_t)x->rows * 2);
+    RUN(launch_layernorm_fwd(dtype, x->p, nm.gamma, nm.beta, y->p, st, (int)x->rows, x->cols, nm.eps, stream));
+    y->ng = x->ng;
+    if (saving && y->ng) {
+      const Norm* np = &nm;
+      tape.push_back([=]() {
+        if (!y->g) return;
+        bool had;
+        void* dx = grad_slot(x, had);
+        RUN(launch_layernorm_bwd(dtype, x->p, y->g, np->gamma, st, had ? dx : nullptr, dx, (int)x->rows, x->cols,
+                                 stream));
+      });
+    }
+    return y;
+  }
+
+  Ten* groupnorm(Ten* x, const Norm& nm, bool silu) {
+    const int HW = x->H * x->W, G = cfg.norm_num_groups, C = x->cols;
+    Ten* y = new_ten(x->rows, C, x->n, x->H, x->W);
+    float* ab = alloc_f32((size_t)2 * x->n * C);
+    float* mr = alloc_f32((size_t)x->n * G * 2);
+    const size_t npart = (size_t)x->n * gn_num_chunks(HW) * G * 2;
+    float* part = alloc_f32(npart);
+    RUN(launch_groupnorm_fwd(dtype, x->p, nm.gamma, nm.beta, y->p, ab, mr, part, x->n, HW, C, G, nm.eps, silu ? 1 : 0,
+                             stream));
+    y->ng = x->ng;
+    if (saving && y->ng) {
+      const Norm* np = &nm;
+      tape.push_back([=]() {
+        if (!y->g) return;
+        bool had;
+        void* dx = grad_slot(x, had);
+        float* scr = alloc_f32(npart + (size_t)2 * x->n * C);
+        RUN(launch_groupnorm_bwd(dtype, x->p, y->g, np->gamma, np->beta, ab, mr, had ? dx : nullptr, dx, scr, x->n, HW,
+                                 C, G, silu ? 1 : 0, stream));
+      });
+    }
+    return y;
+  }
+
+  Ten* geglu(Ten* pj) {
+    const int C4 = pj->cols / 2;
+    Ten* y = new_ten(pj->rows, C4, pj->n, pj->H, pj->W);
+    RUN(launch_geglu_fwd(dtype, pj->p, y->p, (int)pj->rows, C4, stream));
+    y->ng = pj->ng;
+    if (saving && y->ng) {
+      tape.push_back([=]() {
+        if (!y->g) return;
+        bool had;
+        void* dp = grad_slot(pj, had);
+        if (had) {  // never happens in this graph (proj has a single consumer); kept for safety
+          void* tmp = alloc_t(pj->rows, pj->cols);
+          RUN(launch_geglu_bwd(dtype, pj->p, y->g, tmp, (int)pj->rows, C4, stream));
+          RUN(launch_add(dtype, dp, tmp, dp, pj->rows * pj->cols, stream));
+        } else {
+          RUN(launch_geglu_bwd(dtype, pj->p, y->g, dp, (int)pj->rows, C4, stream));
+        }
+      });
+    }
+    return y;
+  }
+
+  // self-attention on a fused [M, 3C] q|k|v tensor, or cross-attention on q [M, C] and kv [n*L, 2C]
+  Ten* attention(Ten* qkv, Ten* q, Ten* kv, int heads, int C, int nbatch, int Nq, int Nk) {
+    Ten* src_q = qkv ? qkv : q;
+    Ten* o = new_ten(src_q->rows, C, src_q->n, src_q->H, src_q->W);
+    float* lse = alloc_f32((size_t)nbatch * heads * Nq);
+    AttnParams p;
+    p.dtype = dtype;
+    p.B = nbatch;
+    p.H = heads;
+    p.Nq = Nq;
+    p.Nk = Nk;
+    p.D = C / heads;
+    p.scale = 1.f / sqrtf((float)p.D);
+    if (qkv) {
+      p.Q = qkv->p;
+      p.K = (char*)qkv->p + (size_t)C * esz();
+      p.V = (char*)qkv->p + (size_t)2 * C * esz();
+      p.ldq = p.ldk = p.ldv = 3 * C;
+    } else {
+      p.Q = q->p;
+      p.ldq = C;
+      p.K = kv->p;
+      p.V = (char*)kv->p + (size_t)C * esz();
+      p.ldk = p.ldv = 2 * C;
+    }
+    p.O = o->p;
+    p.ldo = C;
+    p.lse = lse;
+    RUN(launch_attn_fwd(p, stream));
+    o->ng = qkv ? qkv->ng : (q->ng || kv->ng);
+    if (saving && o->ng) {
+      tape.push_back([=]() {
+        if (!o->g) return;
+        AttnParams b = p;
+        b.dO = o->g;
+        b.lddo = C;
+        b.delta = alloc_f32((size_t)nbatch * heads * Nq);
+        bool had;
+        if (qkv) {
+          char* g = (char*)grad_slot(qkv, had);
+          b.dQ = g;
+          b.dK = g + (size_t)C * esz();
+          b.dV = g + (size_t)2 * C * esz();
+          b.lddq = b.lddk = b.lddv = 3 * C;
+        } else {
+          if (q->ng) {
+            b.dQ = grad_slot(q, had);
+            b.lddq = C;
+          }
+          if (kv->ng) {
+            char* g = (char*)grad_slot(kv, had);
+            b.dK = g;
+            b.dV = g + (size_t)C * esz();
+            b.lddk = b.lddv = 2 * C;
+          }
+        }
+        RUN(launch_attn_bwd(b, stream));
+      });
+    }
+    return o;
+  }
+
+  // 3x3 conv (pad 1): mode 0 stride 1, 1 stride 2, 2 nearest-2x upsample then stride 1
+  Ten* conv3x3(Ten* x, const Conv& c, Ten* rowvec, Ten* res) {
+    const int Hin = x->H, Win = x->W;
+    const int Hout = c.mode == 1 ? (Hin + 1) / 2 : (c.mode == 2 ? Hin * 2 : Hin);
+    const int Wout = c.mode == 1 ? (Win + 1) / 2 : (c.mode == 2 ? Win * 2 : Win);
+    Ten* y = new_ten((int64_t)x->n * Hout * Wout, c.Cout, x->n, Hout, Wout);
+    GemmParams p;
+    p.dtype = dtype;
+    p.conv = 1;
+    p.A = x->p;
+    p.W = c.Wp;
+    p.C = y->p;
+    p.ldc = c.Cout;
+    p.M = (int)y->rows;
+    p.N = c.Cout;
+    p.K = 9 * c.Cin;
+    p.bias = c.b;
+    p.Nb = x->n;
+    p.Hin = Hin;
+    p.Win = Win;
+    p.Cin = c.Cin;
+    p.Hout = Hout;
+    p.Wout = Wout;
+    p.stride = c.mode == 1 ? 2 : 1;
+    p.upsample = c.mode == 2 ? 1 : 0;
+    if (rowvec) {
+      p.rowvec = rowvec->p;
+      p.rows_per_vec = Hout * Wout;
+    }
+    if (res) {
+      p.res = res->p;
+      p.ldr = res->cols;
+    }
+    RUN(launch_gemm(p, stream));
+    y->ng = x->ng || (res && res->ng);
+    if (saving && y->ng) {
+      const Conv* cp = &c;
+      tape.push_back([=]() {
+        void* dy = y->g;
+        if (!dy) return;
+        if (res && res->ng) accumulate(res, dy);
+        if (!x->ng) return;
+        bool had;
+        void* dx = grad_slot(x, had);
+        GemmParams b;
+        b.dtype = dtype;
+        b.conv = 1;
+        b.A = dy;
+        b.W = cp->Wg;
+        b.N = cp->Cin;
+        b.K = 9 * cp->Cout;
+        b.Cin = cp->Cout;
+        b.Nb = x->n;
+        b.ldc = cp->Cin;
+        if (cp->mode == 0) {
+          b.Hin = b.Hout = Hin;
+          b.Win = b.Wout = Win;
+          b.M = (int)x->rows;
+          b.C = dx;
+          if (had) {
+            b.res = dx;
+            b.ldr = cp->Cin;
+          }
+          RUN(launch_gemm(b, stream));
+        } else if (cp->mode == 1) {  // gradient of the stride-2 conv: gather dY at (i + 1 - k) / 2
+          b.Hin = Hout;
+          b.Win = Wout;
+          b.Hout = Hin;
+          b.Wout = Win;
+          b.stride = 2;
+          b.transposed = 1;
+          b.M = (int)x->rows;
+          b.C = dx;
+          if (had) {
+            b.res = dx;
+            b.ldr = cp->Cin;
+          }
+          RUN(launch_gemm(b, stream));
+        } else {  // upsample + conv: gradient on the 2x grid, then 2x2 sum-pool
+          void* du = alloc_t(y->rows, cp->Cin);
+          b.Hin = b.Hout = Hout;
+          b.Win = b.Wout = Wout;
+          b.M = (int)y->rows;
+          b.C = du;
+          RUN(launch_gemm(b, stream));
+          if (had) {
+            void* tmp = alloc_t(x->rows, cp->Cin);
+            RUN(launch_pool2x2_sum(dtype, du, tmp, x->n, Hin, Win, cp->Cin, stream));
+            RUN(launch_add(dtype, dx, tmp, dx, x->rows * x->cols, stream));
+          } else {
+            RUN(launch_pool2x2_sum(dtype, du, dx, x->n, Hin, Win, cp->Cin, stream));
+          }
+        }
+      });
+    }
+    return y;
+  }
+
+  Ten* concat(Ten* a, Ten* b) {
+    Ten* y = new_ten(a->rows, a->cols + b->cols, a->n, a->H, a->W);
+    RUN(launch_copy_cols(dtype, a->p, a->cols, y->p, y->cols, 0, (int)a->rows, a->cols, stream));
+    RUN(launch_copy_cols(dtype, b->p, b->cols, y->p, y->cols, a->cols, (int)a->rows, b->cols, stream));
+    y->ng = a->ng || b->ng;
+    if (saving && y->ng) {
+      tape.push_back([=]() {
+        if (!y->g) return;
+        Ten* parts[2] = {a, b};
+        int col0 = 0;
+        for (int i = 0; i < 2; ++i) {
+          Ten* t = parts[i];
+          if (t->ng) {
+            bool had;
+            void* dst = grad_slot(t, had);
+            if (had) {
+              void* tmp = alloc_t(t->rows, t->cols);
+              RUN(launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, tmp, t->cols, 0, (int)t->rows,
+                                   t->cols, stream));
+              RUN(launch_add(dtype, dst, tmp, dst, t->rows * t->cols, stream));
+            } else {
+              RUN(launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, dst, t->cols, 0, (int)t->rows,
+                                   t->cols, stream));
+            }
+          }
+          col0 += t->cols;
+        }
+      });
+    }
+    return y;
+  }
+
+  Ten* silu(Ten* x) {  // only used on the (gradient-free) time embedding path
+    Ten* y = new_ten(x->rows, x->cols, x->n, x->H, x->W);
+    RUN(launch_silu(dtype, x->p, y->p, x->rows * x->cols, stream));
+    return y;
+  }
+
+  Ten* resnet(Ten* x, const Resnet& r, Ten* temb_act) {
+    Ten* h = groupnorm(x, r.n1, true);
+    Ten* t = linear(temb_act, r.temb);
+    h = conv3x3(h, r.c1, t, nullptr);
+    h = groupnorm(h, r.n2, true);
+    Ten* sc = r.has_sc ? linear(x, r.sc) : x;
+    return conv3x3(h, r.c2, nullptr, sc);
+  }
+
+  Ten* transformer(Ten* x, const Transformer& t, Ten* ctx) {
+    const int C = t.C, nb = x->n, Nq = x->H * x->W;
+    Ten* h = groupnorm(x, t.norm, false);
+    h = linear(h, t.proj_in);
+    for (const TBlock& tb : t.blocks) {
+      Ten* nrm = layernorm(h, tb.n1);
+      Ten* qkv = linear(nrm, tb.qkv1);
+      Ten* o = attention(qkv, nullptr, nullptr, t.heads, C, nb, Nq, Nq);
+      h = linear(o, tb.out1, h);
+      nrm = layernorm(h, tb.n2);
+      Ten* q = linear(nrm, tb.q2);
+      Ten* kv = linear(ctx, tb.kv2);
+      o = attention(nullptr, q, kv, t.heads, C, nb, Nq, ctx_len);
+      h = linear(o, tb.out2, h);
+      nrm = layernorm(h, tb.n3);
+      Ten* pj = linear(nrm, tb.ff1);
+      Ten* gg = geglu(pj);
+      h = linear(gg, tb.ff2, h);
+    }
+    return linear(h, t.proj_out, x);
+  }
+
+  // ---------------------------------------------------------------------------------------------------------
+  // whole passes
+  // ---------------------------------------------------------------------------------------------------------
+  int forward(int n, const float* sample, float timestep, const void* ctxp, const void* text_embeds,
+              const float* time_ids, bool save, float* eps_out) {
+    cur = &arena[save ? 1 : 0];
+    cur->reset();
+    if (save) {
+      tape.clear();
+      tape_valid = false;
+    }
+    tens = &tens_[save ? 1 : 0];
+    tens->clear();
+    saving = save;
+    const int H = lat_h, Wd_ = lat_w, HW = H * Wd_;
+    const int C0 = cfg.block_out_channels[0];
+    const int ted = C0 * 4;
+
+    // ---- time / added-condition embedding (no gradient flows here: not adapted under lierla)
+    float* tvals = alloc_f32(n);
+    if (!dry && !err) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, stream, tvals, timestep, n);
+    Ten* te = new_ten(n, C0);
+    RUN(launch_timestep_embed(dtype, tvals, te->p, n, C0, stream));
+    Ten* emb = linear(silu(linear(te, time1)), time2);
+    if (cfg.addition_embed) {
+      const int P = cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim;
+      Ten* tid = new_ten(n, 6 * cfg.addition_time_embed_dim);
+      RUN(launch_timestep_embed(dtype, time_ids, tid->p, n * 6, cfg.addition_time_embed_dim, stream));
+      Ten* cat = new_ten(n, cfg.projection_class_embeddings_input_dim);
+      Ten pooled;
+      pooled.p = const_cast<void*>(text_embeds);
+      RUN(launch_copy_cols(dtype, pooled.p, P, cat->p, cat->cols, 0, n, P, stream));
+      RUN(launch_copy_cols(dtype, tid->p, tid->cols, cat->p, cat->cols, P, n, tid->cols, stream));
+      Ten* aug = linear(silu(linear(cat, add1)), add2);
+      Ten* sum = new_ten(n, ted);
+      RUN(launch_add(dtype, emb->p, aug->p, sum->p, (int64_t)n * ted, stream));
+      emb = sum;
+    }
+    Ten* temb_act = silu(emb);
+
+    // ---- context as a [n*L, D] tensor (borrowed)
+    tens->emplace_back();
+    Ten* ctx = &tens->back();
+    ctx->p = const_cast<void*>(ctxp);
+    ctx->rows = (int64_t)n * ctx_len;
+    ctx->cols = cfg.cross_attention_dim;
+    ctx->n = n;
+
+    // ---- conv_in
+    Ten* x0 = new_ten((int64_t)n * HW, cfg.in_channels, n, H, Wd_);
+    RUN(launch_nchw_to_nhwc(dtype, sample, 1, x0->p, n, cfg.in_channels, HW, cfg.in_channels, 1.f, stream));
+    Ten* h = new_ten((int64_t)n * HW, C0, n, H, Wd_);
+    RUN(launch_conv3x3_small(dtype, x0->p, conv_in.Wp, conv_in.b, h->p, 0, n, H, Wd_, cfg.in_channels, C0, stream));
+
+    std::vector<Ten*> skips;
+    skips.push_back(h);
+    for (size_t i = 0; i < down.size(); ++i) {
+      Level& lv = down[i];
+      for (size_t j = 0; j < lv.res.size(); ++j) {
+        h = resnet(h, lv.res[j], temb_act);
+        if (lv.has_att) h = transformer(h, lv.att[j], ctx);
+        skips.push_back(h);
+      }
+      if (lv.has_samp) {
+        h = conv3x3(h, lv.samp, nullptr, nullptr);
+        skips.push_back(h);
+      }
+    }
+    h = resnet(h, mid.res[0], temb_act);
+    h = transformer(h, mid.att[0], ctx);
+    h = resnet(h, mid.res[1], temb_act);
+    for (size_t i = 0; i < up.size(); ++i) {
+      Level& lv = up[i];
+      for (size_t j = 0; j < lv.res.size(); ++j) {
+        Ten* sk = skips.back();
+        skips.pop_back();
+        h = concat(h, sk);
+        h = resnet(h, lv.res[j], temb_act);
+        if (lv.has_att) h = transformer(h, lv.att[j], ctx);
+      }
+      if (lv.has_samp) h = conv3x3(h, lv.samp, nullptr, nullptr);
+    }
+    Ten* hn = groupnorm(h, norm_out, true);
+
+    // ---- conv_out (MFMA path, fp32 result) + NHWC->NCHW
+    Ten* y = new_ten((int64_t)n * HW, cfg.out_channels, n, H, Wd_, sizeof(float));
+    {
+      GemmParams p;
+      p.dtype = dtype;
+      p.conv = 1;
+      p.A = hn->p;
+      p.W = conv_out.Wp;
+      p.C = y->p;
+      p.ldc = cfg.out_channels;
+      p.out_f32 = 1;
+      p.M = (int)y->rows;
+      p.N = cfg.out_channels;
+      p.K = 9 * C0;
+      p.bias = conv_out.b;
+      p.Nb = n;
+      p.Hin = p.Hout = H;
+      p.Win = p.Wout = Wd_;
+      p.Cin = C0;
+      RUN(launch_gemm(p, stream));
+    }
+    RUN(launch_nhwc_to_nchw_f32((const float*)y->p, eps_out, n, cfg.out_channels, HW, stream));
+    y->ng = hn->ng;
+    if (saving && y->ng) {
+      tape.push_back([=]() {
+        if (!y->g) return;
+        bool had;
+        void* dx = grad_slot(hn, had);
+        RUN(launch_conv3x3_small(dtype, y->g, conv_out.Wg, nullptr, dx, 0, n, H, Wd_, cfg.out_channels, C0, stream));
+      });
+    }
+    if (save) {
+      out_ten = y;
+      last_n = n;
+      bw_down = lora_down;
+      bw_up = lora_up;
+      tape_valid = true;
+    }
+    saving = false;
+    if (cur->overflow && !dry) {
+      set_error("workspace too small for this call (arena %d needs %zu bytes, has %zu)", save ? 1 : 0, cur->peak,
+                cur->cap);
+      return -3;
+    }
+    return err ? -1 : 0;
+  }
+
+  int backward(const float* d_eps, float* dd, float* du) {
+    if (!tape_valid && !dry) {
+      set_error("smi_unet_backward: no saved forward pass (call smi_unet_forward with save_for_backward=1 first)");
+      return -4;
+    }
+    cur = &arena[1];
+    tens = &tens_[1];
+    d_down = dd;
+    d_up = du;
+    const int n = last_n, HW = lat_h * lat_w;
+    Ten* y = out_ten;
+    if (!y->ng) return 0;  // adaptor off: nothing depends on the LoRA parameters
+    const int64_t cnt = (int64_t)n * cfg.out_channels * HW;
+    RUN(launch_grad_scale(d_eps, cnt, gscale, stream));
+    y->g = alloc_t(y->rows, cfg.out_channels);
+    RUN(launch_nchw_to_nhwc_scaled(dtype, d_eps, y->g, n, cfg.out_channels, HW, cfg.out_channels, gscale, stream));
+    for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();
+    tape.clear();
+    tape_valid = false;
+    if (cur->overflow && !dry) {
+      set_error("workspace too small for the backward (needs %zu bytes, has %zu)", cur->peak, cur->cap);
+      return -3;
+    }
+    return err ? -1 : 0;
+  }
+};
+
+// ==============================================================================================================
+// C ABI
+// ==============================================================================================================
+namespace {
+
+int check_cfg(const smi_unet_config* c) {
+  SMI_CHECK(c != nullptr, "config is NULL");
+  SMI_CHECK(c->dtype == SMI_DTYPE_F16 || c->dtype == SMI_DTYPE_BF16, "dtype must be f16 (0) or bf16 (1)");
+  SMI_CHECK(c->n_levels >= 1 && c->n_levels <= SMI_MAX_LEVELS, "n_levels out of range");
+  SMI_CHECK(c->in_channels >= 1 && c->in_channels <= 16 && c->out_channels == 4, "in/out channels unsupported");
+  for (int i = 0; i < c->n_levels; ++i) {
+    SMI_CHECK(c->block_out_channels[i] % 64 == 0, "block_out_channels must be multiples of 64 (MFMA K tile)");
+    SMI_CHECK(c->block_out_channels[i] % c->norm_num_groups == 0, "channels must divide by norm_num_groups");
+    SMI_CHECK(c->num_heads[i] > 0 && c->block_out_channels[i] % c->num_heads[i] == 0, "heads must divide channels");
+    SMI_CHECK((c->block_out_channels[i] / c->num_heads[i]) % 8 == 0, "head_dim must be a multiple of 8");
+  }
+  SMI_CHECK(c->cross_attention_dim % 8 == 0, "cross_attention_dim %% 8");
+  return 0;
+}
+
+int setup(smi_engine* e, const smi_unet_config* cfg, const smi_weight* weights, int n_weights,
+          const smi_lora_site* sites, int n_sites, int batch, int h, int w, int ctx_len) {
+  e->cfg = *cfg;
+  e->dtype = cfg->dtype;
+  e->max_n = batch;
+  e->lat_h = h;
+  e->lat_w = w;
+  e->ctx_len = ctx_len;
+  for (int i = 0; i < n_weights; ++i) e->wmap[weights[i].name] = &weights[i];
+  e->sites.assign(sites, sites + n_sites);
+  e->site_names.resize(n_sites);
+  e->site_used.assign(n_sites, 0);
+  for (int i = 0; i < n_sites; ++i) {
+    e->site_names[i] = sites[i].target;
+    e->sites[i].target = e->site_names[i].c_str();
+  }
+  for (int i = 0; i < n_sites; ++i) e->smap[e->site_names[i]] = &e->sites[i];
+  return 0;
+}
+
+// dry run: sizes of the three regions
+int plan(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int h, int w, int ctx_len,
+         size_t out[3]) {
+  smi_engine e;
+  e.dry = true;
+  setup(&e, cfg, nullptr, 0, sites, n_sites, batch, h, w, ctx_len);
+  e.build();
+  if (e.err) return -1;
+  out[0] = align_up(e.wpack.peak, 4096);
+  e.forward(batch, nullptr, 0.f, nullptr, nullptr, nullptr, false, nullptr);
+  out[1] = align_up(e.arena[0].peak, 4096);
+  e.forward(batch, nullptr, 0.f, nullptr, nullptr, nullptr, true, nullptr);
+  e.backward(nullptr, nullptr, nullptr);
+  out[2] = align_up(e.arena[1].peak, 4096);
+  return e.err ? -1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* smi_last_error(void) { return g_err; }
+
+int smi_workspace_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int h, int w,
+                        int ctx_len, size_t* bytes) {
+  if (check_cfg(cfg)) return -1;
+  SMI_CHECK(bytes && batch > 0 && h > 0 && w > 0 && ctx_len > 0, "bad arguments");
+  size_t r[3];
+  if (plan(cfg, sites, n_sites, batch, h, w, ctx_len, r)) return -1;
+  *bytes = r[0] + r[1] + r[2] + 3 * 4096;
+  return 0;
+}
+
+int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weights, const smi_lora_site* sites,
+               int n_sites, int batch, int h, int w, int ctx_len, void* workspace, size_t workspace_bytes,
+               void* stream, smi_engine** out) {
+  if (check_cfg(cfg)) return -1;
+  SMI_CHECK(out && workspace && weights && n_weights > 0, "bad arguments");
+  size_t r[3];
+  if (plan(cfg, sites, n_sites, batch, h, w, ctx_len, r)) return -1;
+  SMI_CHECK(r[0] + r[1] + r[2] + 3 * 4096 <= workspace_bytes, "workspace too small: need %zu bytes, got %zu",
+            r[0] + r[1] + r[2] + 3 * 4096, workspace_bytes);
+  smi_engine* e = new smi_engine();
+  e->stream = (hipStream_t)stream;
+  setup(e, cfg, weights, n_weights, sites, n_sites, batch, h, w, ctx_len);
+  char* base = (char*)align_up((size_t)workspace, 4096);
+  e->ws = (char*)workspace;
+  e->ws_bytes = workspace_bytes;
+  e->wpack.base = base;
+  e->wpack.cap = r[0];
+  e->arena[0].base = base + r[0];
+  e->arena[0].cap = r[1];
+  e->arena[1].base = base + r[0] + r[1];
+  e->arena[1].cap = r[2];
+  e->build();
+  if (e->err || hipGetLastError() != hipSuccess) {
+    if (!e->err) set_error("HIP error while packing weights");
+    delete e;
+    return -1;
+  }
+  // the weight table is only borrowed during creation
+  e->wmap.clear();
+  *out = e;
+  return 0;
+}
+
+void smi_destroy(smi_engine* e) { delete e; }
+
+int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, const void* ctx,
+                     const void* text_embeds, const float* time_ids, const float* lora_down_flat,
+                     const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out) {
+  SMI_CHECK(e && sample && ctx && eps_out, "NULL argument");
+  SMI_CHECK(n >= 1 && n <= e->max_n, "batch %d outside [1, %d] the engine was created for", n, e->max_n);
+  SMI_CHECK(!e->cfg.addition_embed || (text_embeds && time_ids), "SD-XL engine needs text_embeds and time_ids");
+  e->err = false;
+  e->lora_down = lora_down_flat;
+  e->lora_up = lora_up_flat;
+  e->mult = (lora_down_flat && lora_up_flat) ? multiplier : 0.f;
+  return e->forward(n, sample, timestep, ctx, text_embeds, time_ids, save_for_backward != 0, eps_out);
+}
+
+int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat, float* d_lora_up_flat) {
+  SMI_CHECK(e && d_eps && d_lora_down_flat && d_lora_up_flat, "NULL argument");
+  e->err = false;
+  return e->backward(d_eps, d_lora_down_flat, d_lora_up_flat);
+}
+
+int smi_cfg_combine(const float* eps_2n, float* out_n, int64_t n_half, float g, void* stream) {
+  return launch_cfg_combine(eps_2n, out_n, n_half, g, (hipStream_t)stream);
+}
+int smi_slider_loss(const float* target, const float* positive, const float* neutral, const float* negative,
+                    float sign_eta, int64_t n, float* loss_out, float* dtarget, float* scratch, void* stream) {
+  return launch_slider_loss(target, positive, neutral, negative, sign_eta, n, loss_out, dtarget, scratch,
+                            (hipStream_t)stream);
+}
+int smi_clip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float max_norm, float* scratch,
+                   void* stream) {
+  return launch_clip_adamw(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, max_norm,
+                           scratch, (hipStream_t)stream);
+}
+int smi_sched_step(float* x, const float* eps, const float* noise, float c_x, float c_eps, float c_noise, int64_t n,
+                   void* stream) {
+  return launch_sched_affine(x, eps, noise, c_x, c_eps, c_noise, n, (hipStream_t)stream);
+}
+
+// ---- single-kernel entry points for the parity tests -----------------------------------------------------------
+int smi_op_gemm(int dtype, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
+                const void* res, const float* lora_xa, const float* lora_up, int lora_r, float lora_scale,
+                int out_f32, void* stream) {
+  GemmParams p;
+  p.dtype = dtype;
+  p.A = A;
+  p.lda = K;
+  p.W = W;
+  p.C = C;
+  p.ldc = N;
+  p.out_f32 = out_f32;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.bias = bias;
+  p.res = res;
+  p.ldr = N;
+  p.lora_xa = lora_xa;
+  p.ld_xa = lora_r;
+  p.lora_up = lora_up;
+  p.up_sn = lora_r;
+  p.up_sq = 1;
+  p.lora_r = lora_xa ? lora_r : 0;
+  p.lora_scale = lora_scale;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+int smi_op_conv3x3(int dtype, const void* in, const void* w_packed, const void* bias, void* out, int nb, int hin,
+                   int win, int cin, int cout, int stride, int upsample, int transposed, int hout, int wout,
+                   void* stream) {
+  GemmParams p;
+  p.dtype = dtype;
+  p.conv = 1;
+  p.A = in;
+  p.W = w_packed;
+  p.C = out;
+  p.ldc = cout;
+  p.M = nb * hout * wout;
+  p.N = cout;
+  p.K = 9 * cin;
+  p.bias = bias;
+  p.Nb = nb;
+  p.Hin = hin;
+  p.Win = win;
+  p.Cin = cin;
+  p.Hout = hout;
+  p.Wout = wout;
+  p.stride = stride;
+  p.upsample = upsample;
+  p.transposed = transposed;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+int smi_op_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int b, int h,
+                         int nq, int nk, int d, float scale, void* stream) {
+  AttnParams p;
+  p.dtype = dtype;
+  p.Q = q;
+  p.K = k;
+  p.V = v;
+  p.O = o;
+  p.lse = lse;
+  p.ldq = p.ldk = p.ldv = p.ldo = (int64_t)h * d;
+  p.B = b;
+  p.H = h;
+  p.Nq = nq;
+  p.Nk = nk;
+  p.D = d;
+  p.scale = scale;
+  return launch_attn_fwd(p, (hipStream_t)stream);
+}
+int smi_op_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                         const void* d_o, void* dq, void* dk, void* dv, float* delta, int b, int h, int nq, int nk,
+                         int d, float scale, void* stream) {
+  AttnParams p;
+  p.dtype = dtype;
+  p.Q = q;
+  p.K = k;
+  p.V = v;
+  p.O = const_cast<void*>(o);
+  p.lse = const_cast<float*>(lse);
+  p.ldq = p.ldk = p.ldv = p.ldo = p.lddo = p.lddq = p.lddk = p.lddv = (int64_t)h * d;
+  p.dO = d_o;
+  p.dQ = dq;
+  p.dK = dk;
+  p.dV = dv;
+  p.delta = delta;
+  p.B = b;
+  p.H = h;
+  p.Nq = nq;
+  p.Nk = nk;
+  p.D = d;
+  p.scale = scale;
+  return launch_attn_bwd(p, (hipStream_t)stream);
+}
+// scratch layout (floats): ab[2*nb*c] | mean_rstd[nb*g*2] | partial[...]
+int smi_op_groupnorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
+                     float* scratch, int nb, int hw, int c, int g, float eps, int silu, void* stream) {
+  float* ab = scratch;
+  float* mr = ab + (size_t)2 * nb * c;
+  float* part = mr + (size_t)nb * g * 2;
+  int rc = launch_groupnorm_fwd(dtype, x, gamma, beta, y, ab, mr, part, nb, hw, c, g, eps, silu, (hipStream_t)stream);
+  if (rc || !dy) return rc;
+  return launch_groupnorm_bwd(dtype, x, dy, gamma, beta, ab, mr, nullptr, dx, part, nb, hw, c, g, silu,
+                              (hipStream_t)stream);
+}
+int smi_op_layernorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
+                     float* mean_rstd, int m, int c, float eps, void* stream) {
+  int rc = launch_layernorm_fwd(dtype, x, gamma, beta, y, mean_rstd, m, c, eps, (hipStream_t)stream);
+  if (rc || !dy) return rc;
+  return launch_layernorm_bwd(dtype, x, dy, gamma, mean_rstd, nullptr, dx, m, c, (hipStream_t)stream);
+}
+int smi_op_geglu(int dtype, const void* proj, void* out, const void* dout, void* dproj, int m, int c4, void* stream) {
+  int rc = launch_geglu_fwd(dtype, proj, out, m, c4, (hipStream_t)stream);
+  if (rc || !dout) return rc;
+  return launch_geglu_bwd(dtype, proj, dout, dproj, m, c4, (hipStream_t)stream);
+}
+int smi_op_lora_down(int dtype, const void* x, const float* a, float* xa, int m, int k, int r, void* stream) {
+  return launch_lora_down(dtype, x, k, a, k, 1, xa, r, m, k, r, (hipStream_t)stream);
+}
+int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m, int k, int r, float alpha,
+                      float* scratch, void* stream) {
+  return launch_lora_wgrad(dtype, p, r, x, k, dw, k, 1, m, k, r, alpha, nullptr, scratch, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,335 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950.
+//
+//   C[M,N] = A[M,K] * W[N,K]^T + epilogue            (both operands K-contiguous: "NT")
+//
+// Tile: 128(M) x 128(N) x 64(K), 256 threads = 4 waves in a 2x2 grid, each wave 64x64 as 4x4 tiles of
+// v_mfma_f32_16x16x32_{f16,bf16}.  Operands are staged global -> registers -> LDS (one 16-byte chunk per lane per
+// load, XOR-swizzled 128-byte LDS rows, conflict-free ds_read_b128 fragment reads), with the next K-tile's global
+// loads in flight under the current tile's MFMAs.  The MFMA is issued as D = W_frag x A_frag so that each lane
+// ends up with 4 consecutive output columns (n) of one row (m): 8-byte (T) / 16-byte (f32) stores and a vector
+// epilogue (bias, per-image row vector, LoRA rank-r delta, residual) in fp32 before the single rounding.
+//
+// Convolution: the A operand is gathered straight from the NHWC activation (no im2col buffer):
+// row m = (image, oy, ox), K index = (ky, kx, ci).  Cin % 64 == 0 keeps every 64-wide K step inside one filter tap,
+// so the tap geometry is wave-uniform scalar work; padding, tails and strided/transposed/up-sampled taps turn
+// into out-of-range buffer offsets, which the hardware range check returns as zeros.
+#include "kernels.h"
+
+namespace smi {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct ConvRow {
+  int base;  // image index * Hin * Win  (pixels)
+  int oy, ox;
+};
+
+template <typename T, bool CONV>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * BK * 2];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + BM * BK * 2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap of the linear block id: blocks that share an XCD (id % 8) get a contiguous
+  // range of tiles, so neighbouring tiles (same A rows / same W rows) hit the same L2.
+  const int nbn = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int wg;
+  {
+    const int orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int bm0 = (wg / nbn) * BM;
+  const int bn0 = (wg % nbn) * BN;
+
+  const uint32_t esz = 2;
+  __amdgpu_buffer_rsrc_t rA, rW;
+  if (CONV) {
+    rA = make_rsrc(p.A, (uint32_t)((int64_t)p.Nb * p.Hin * p.Win * p.Cin * esz));
+  } else {
+    rA = make_rsrc(p.A, (uint32_t)(((int64_t)(p.M - 1) * p.lda + p.K) * esz));
+  }
+  rW = make_rsrc(p.W, (uint32_t)((int64_t)p.N * p.K * esz));
+
+  // ---- staging assignment: thread -> chunk (16 B) c of rows r0 + 32*i
+  const int sc = tid & 7;
+  const int sr = tid >> 3;
+  ConvRow crow[4];
+  uint32_t a_rowoff[4];
+  uint32_t w_rowoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm0 + sr + 32 * i;
+    if (CONV) {
+      if (m < p.M) {
+        const int hw = p.Hout * p.Wout;
+        const int img = m / hw;
+        const int rem = m - img * hw;
+        crow[i].base = img * p.Hin * p.Win;
+        crow[i].oy = rem / p.Wout;
+        crow[i].ox = rem - crow[i].oy * p.Wout;
+      } else {
+        crow[i].base = 0;
+        crow[i].oy = -(1 << 20);
+        crow[i].ox = -(1 << 20);
+      }
+      a_rowoff[i] = 0;
+    } else {
+      a_rowoff[i] = (m < p.M) ? (uint32_t)((int64_t)m * p.lda * esz) : OOB;
+    }
+    const int n = bn0 + sr + 32 * i;
+    w_rowoff[i] = (n < p.N) ? (uint32_t)((int64_t)n * p.K * esz) : OOB;
+  }
+
+  u32x4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    const int kc = k0 + sc * 8;
+    const bool kok = kc < p.K;
+    if (CONV) {
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int iy, ix;
+        bool ok;
+        if (p.transposed) {
+          const int ty = crow[i].oy + 1 - ky, tx = crow[i].ox + 1 - kx;
+          iy = ty / p.stride;
+          ix = tx / p.stride;
+          ok = (ty >= 0) && (tx >= 0) && (iy * p.stride == ty) && (ix * p.stride == tx) && (iy < p.Hin) &&
+               (ix < p.Win);
+        } else {
+          iy = crow[i].oy * p.stride + ky - 1;
+          ix = crow[i].ox * p.stride + kx - 1;
+          if (p.upsample) {
+            ok = (iy >= 0) && (ix >= 0) && (iy < 2 * p.Hin) && (ix < 2 * p.Win);
+            iy >>= 1;
+            ix >>= 1;
+          } else {
+            ok = (iy >= 0) && (ix >= 0) && (iy < p.Hin) && (ix < p.Win);
+          }
+        }
+        const uint32_t off = ok ? (uint32_t)(((crow[i].base + iy * p.Win + ix) * (int64_t)p.Cin + c0 + sc * 8) * esz)
+                                : OOB;
+        ra[i] = buf_load16(rA, off);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t off = (kok && a_rowoff[i] != OOB) ? a_rowoff[i] + (uint32_t)kc * esz : OOB;
+        ra[i] = buf_load16(rA, off);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t off = (kok && w_rowoff[i] != OOB) ? w_rowoff[i] + (uint32_t)kc * esz : OOB;
+      rb[i] = buf_load16(rW, off);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = sr + 32 * i;
+      const int off = r * 128 + ((sc ^ (r & 7)) << 4);
+      *reinterpret_cast<u32x4*>(As + off) = ra[i];
+      *reinterpret_cast<u32x4*>(Bs + off) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      typename TT<T>::v8 xa[4], wb[4];
+      const int ch = kk * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rm = wm * 64 + i * 16 + fr;
+        Pack8<T> t;
+        t.u = *reinterpret_cast<const u32x4*>(As + rm * 128 + ((ch ^ (rm & 7)) << 4));
+        xa[i] = t.v;
+        const int rn = wn * 64 + i * 16 + fr;
+        Pack8<T> s;
+        s.u = *reinterpret_cast<const u32x4*>(Bs + rn * 128 + ((ch ^ (rn & 7)) << 4));
+        wb[i] = s.v;
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = TT<T>::mfma16(wb[ni], xa[mi], acc[ni][mi]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, per (ni, mi), rows n = nb + 4*fq + {0..3} (MFMA row) of column m = mb + fr
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = bm0 + wm * 64 + mi * 16 + fr;
+    if (m >= p.M) continue;
+    const float* xrow0 = p.lora_xa + (int64_t)m * p.ld_xa;
+    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = bn0 + wn * 64 + ni * 16 + fq * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+      if (p.bias) {
+        Pack4<T> b;
+        b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.bias) + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+      }
+      if (p.rowvec) {
+        Pack4<T> b;
+        b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.rowvec) + vrow + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+      }
+      if (p.lora_r > 0) {
+        const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
+          float d = 0.f;
+          for (int q = 0; q < p.lora_r; ++q) d += xrow[q] * up[q * p.up_sq];
+          v[j] += d * p.lora_scale;
+        }
+      }
+      if (p.res) {
+        Pack4<T> b;
+        b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) =
+            f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        Pack4<T> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.e[j] = from_f<T>(v[j]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) = o.u;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// direct 3x3 conv, stride 1, pad 1, for very small Cin or Cout (conv_in 4->C, conv_out C->4 and gradients).
+// One thread = one output pixel x 4 output channels; weights T [Cout][9*Cin].
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const T* __restrict__ in, const T* __restrict__ w,
+                                                            const T* __restrict__ bias, void* out, int out_f32,
+                                                            int Nb, int H, int W, int Cin, int Cout) {
+  const int cg = (Cout + 3) / 4;
+  const int64_t total = (int64_t)Nb * H * W * cg;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % cg);
+    const int64_t pix = idx / cg;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((int64_t)W * H));
+    const int co0 = g * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = x + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const T* ip = in + (((int64_t)n * H + iy) * W + ix) * Cin;
+        const int kb = (ky * 3 + kx) * Cin;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float v = to_f(ip[ci]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co0 + j < Cout) acc[j] += v * to_f(w[(int64_t)(co0 + j) * 9 * Cin + kb + ci]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (co0 + j >= Cout) continue;
+      float v = acc[j] + (bias ? to_f(bias[co0 + j]) : 0.f);
+      if (out_f32)
+        reinterpret_cast<float*>(out)[pix * Cout + co0 + j] = v;
+      else
+        reinterpret_cast<T*>(out)[pix * Cout + co0 + j] = from_f<T>(v);
+    }
+  }
+}
+
+}  // namespace
+
+int launch_gemm(const GemmParams& p, hipStream_t stream) {
+  SMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
+  SMI_CHECK(p.K % 8 == 0 && p.N % 4 == 0, "gemm: K %% 8 and N %% 4 must be 0 (K=%d N=%d)", p.K, p.N);
+  SMI_CHECK(p.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
+  SMI_CHECK(p.lora_seg % 4 == 0, "gemm: lora_seg %% 4 != 0");
+  SMI_CHECK(p.res == nullptr || p.ldr % 4 == 0, "gemm: ldr %% 4 != 0");
+  if (p.conv) {
+    SMI_CHECK(p.Cin % 64 == 0 && p.K == 9 * p.Cin, "conv: Cin %% 64 != 0 or K != 9*Cin (Cin=%d K=%d)", p.Cin, p.K);
+    SMI_CHECK(p.M == p.Nb * p.Hout * p.Wout, "conv: M != Nb*Hout*Wout");
+    SMI_CHECK((int64_t)p.Nb * p.Hin * p.Win * p.Cin * 2 < 0xFFFFFFF0ll, "conv: input larger than 4 GiB");
+    SMI_CHECK(p.stride == 1 || p.stride == 2, "conv: stride");
+  } else {
+    SMI_CHECK(p.lda % 8 == 0, "gemm: lda %% 8 != 0");
+    SMI_CHECK(((int64_t)(p.M - 1) * p.lda + p.K) * 2 < 0xFFFFFFF0ll, "gemm: A larger than 4 GiB");
+  }
+  SMI_CHECK((int64_t)p.N * p.K * 2 < 0xFFFFFFF0ll, "gemm: W larger than 4 GiB");
+  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  if (p.dtype == DT_F16) {
+    if (p.conv)
+      hipLaunchKernelGGL((gemm_nt_kernel<f16, true>), dim3(grid), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<f16, false>), dim3(grid), dim3(256), 0, stream, p);
+  } else {
+    if (p.conv)
+      hipLaunchKernelGGL((gemm_nt_kernel<bf16, true>), dim3(grid), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<bf16, false>), dim3(grid), dim3(256), 0, stream, p);
+  }
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_conv3x3_small(int dtype, const void* in, const void* w, const void* bias, void* out, int out_f32, int Nb,
+                         int H, int W, int Cin, int Cout, hipStream_t stream) {
+  const int64_t total = (int64_t)Nb * H * W * ((Cout + 3) / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(conv3x3_small_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)in, (const f16*)w,
+                       (const f16*)bias, out, out_f32, Nb, H, W, Cin, Cout);
+  else
+    hipLaunchKernelGGL(conv3x3_small_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)in,
+                       (const bf16*)w, (const bf16*)bias, out, out_f32, Nb, H, W, Cin, Cout);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace smi

@@ -1,0 +1,150 @@
+// Internal launcher API of the HIP kernels (host side).  All launchers enqueue on `stream`, never synchronise,
+// return 0 on success or a negative code after smi::set_error().  Activations are token-major ("NHWC"):
+// an image tensor is [N, H*W, C] with C contiguous.
+#pragma once
+#include "smi_common.h"
+
+namespace smi {
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * W[N,K]^T  (+ epilogue), W rows K-contiguous (torch nn.Linear layout).
+// With conv != 0, A is gathered on the fly from an NHWC image (implicit GEMM, K = 9*Cin ordered (kh,kw,ci)).
+// Epilogue (all fp32, one rounding at the store):  + bias[n] + rowvec[m / rows_per_vec][n]
+//     + lora_scale * sum_q xa[m][q] * up[n][q] + res[m][n]
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmParams {
+  int dtype = DT_F16;
+  const void* A = nullptr;
+  int64_t lda = 0;
+  const void* W = nullptr;
+  void* C = nullptr;
+  int64_t ldc = 0;
+  int out_f32 = 0;
+  int M = 0, N = 0, K = 0;
+  const void* bias = nullptr;    // T [N]
+  const void* res = nullptr;     // T [M, ldr]
+  int64_t ldr = 0;
+  const void* rowvec = nullptr;  // T [M / rows_per_vec, N]
+  int rows_per_vec = 1;
+  // LoRA rank-r delta: + lora_scale * sum_q xa[m*ld_xa + seg*r + q] * up[n*up_sn + q*up_sq], seg = n / lora_seg.
+  // Forward: xa = x*A^T, up = lora_up.weight [N, r] (up_sn = r, up_sq = 1); with fused q|k|v projections the three
+  // [C, r] up matrices are adjacent in the flat buffer and lora_seg = C selects each column block's own xa.
+  // Backward (dX): xa = dY*up, "up" = lora_down.weight [r, K] read transposed (up_sn = 1, up_sq = K).
+  const float* lora_xa = nullptr;
+  int64_t ld_xa = 0;
+  const float* lora_up = nullptr;
+  int64_t up_sn = 0, up_sq = 1;
+  int lora_r = 0;
+  int lora_seg = 0;
+  float lora_scale = 0.f;
+  // implicit-GEMM 3x3 convolution (pad 1)
+  int conv = 0;
+  int Nb = 0, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0;
+  int stride = 1;      // forward: in = out*stride + k - 1
+  int upsample = 0;    // nearest-2x upsample of the input folded into the gather
+  int transposed = 0;  // gradient of a strided conv: out = (in + 1 - k) / stride
+};
+int launch_gemm(const GemmParams& p, hipStream_t stream);
+
+// direct 3x3 conv for tiny channel counts (conv_in: Cin=4; conv_out: Cout=4 and their gradients)
+// in [Nb,H,W,Cin] T ; w f32-free: T [Cout][9*Cin] ; out [Nb,H,W,Cout] (T or f32), stride 1 pad 1
+int launch_conv3x3_small(int dtype, const void* in, const void* w, const void* bias, void* out, int out_f32, int Nb,
+                         int H, int W, int Cin, int Cout, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention: Q [B, Nq, ldq] (head h at column h*D), K/V [B, Nk, ldk/ldv], O [B, Nq, ldo]; lse f32 [B, H, Nq]
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnParams {
+  int dtype = DT_F16;
+  const void *Q = nullptr, *K = nullptr, *V = nullptr;
+  void* O = nullptr;
+  float* lse = nullptr;
+  int64_t ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+  int B = 0, H = 0, Nq = 0, Nk = 0, D = 0;
+  float scale = 1.f;
+  // backward
+  const void* dO = nullptr;
+  int64_t lddo = 0;
+  float* delta = nullptr;  // f32 [B, H, Nq] workspace
+  void *dQ = nullptr, *dK = nullptr, *dV = nullptr;
+  int64_t lddq = 0, lddk = 0, lddv = 0;
+};
+int launch_attn_fwd(const AttnParams& p, hipStream_t stream);
+int launch_attn_bwd(const AttnParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// normalisation
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm over [Nb, HW, C]; writes per-(n,c) affine a,b (f32 [Nb,C] each: y = x*a + b) into `ab` ([2,Nb,C]) and
+// y = (silu?)(x*a+b).  `partial` is scratch f32 [Nb, nchunk, G, 2], nchunk from gn_num_chunks(HW).
+int gn_num_chunks(int HW);
+int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* ab,
+                         float* mean_rstd, float* partial, int Nb, int HW, int C, int G, float eps, int silu,
+                         hipStream_t stream);
+// dx for y = silu?(GN(x)); needs x, gamma, beta, ab and mean_rstd from the forward.
+// `partial`: scratch f32 [Nb*nchunk*G*2 + 2*Nb*C]
+// `add` (optional, may alias dx): gradient already accumulated for x, added in the same pass
+int launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const void* beta,
+                         const float* ab, const float* mean_rstd, const void* add, void* dx, float* partial, int Nb,
+                         int HW, int C, int G, int silu, hipStream_t stream);
+int launch_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean_rstd,
+                         int M, int C, float eps, hipStream_t stream);
+int launch_layernorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const float* mean_rstd,
+                         const void* add, void* dx, int M, int C, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// elementwise / data movement
+// ---------------------------------------------------------------------------------------------------------------
+int launch_geglu_fwd(int dtype, const void* proj, void* out, int M, int C4, hipStream_t stream);  // proj [M, 2*C4]
+int launch_geglu_bwd(int dtype, const void* proj, const void* dout, void* dproj, int M, int C4, hipStream_t stream);
+int launch_silu(int dtype, const void* x, void* y, int64_t n, hipStream_t stream);
+int launch_add(int dtype, const void* a, const void* b, void* y, int64_t n, hipStream_t stream);  // y = a + b
+// copy [M, C] (src row stride lds) into dst columns [col0, col0+C) of a [M, ldd] tensor (concat / split)
+int launch_copy_cols(int dtype, const void* src, int64_t lds, void* dst, int64_t ldd, int col0, int M, int C,
+                     hipStream_t stream);
+int launch_nchw_to_nhwc(int dtype, const void* src, int src_f32, void* dst, int Nb, int C, int HW, int Cpad,
+                        float scale, hipStream_t stream);
+// f32 NCHW -> T token-major, multiplied by the device scalar *scale_dev (backward entry: loss-scaled d_eps)
+int launch_nchw_to_nhwc_scaled(int dtype, const float* src, void* dst, int Nb, int C, int HW, int Cpad,
+                               const float* scale_dev, hipStream_t stream);
+int launch_nhwc_to_nchw_f32(const float* src, float* dst, int Nb, int C, int HW, hipStream_t stream);
+// sinusoidal embedding (cos | sin, flip_sin_to_cos, freq shift 0): vals f32 [n] -> out T [n, dim]
+int launch_timestep_embed(int dtype, const float* vals, void* out, int n, int dim, hipStream_t stream);
+// dx[n,h,w,c] = sum_{2x2} du[n,2h+a,2w+b,c]
+int launch_pool2x2_sum(int dtype, const void* du, void* dx, int Nb, int H, int W, int C, hipStream_t stream);
+// power-of-two loss scale chosen on device from amax|d_eps| (keeps 16-bit activation gradients in range):
+// scale_out[0] = scale, [1] = 1/scale, [2..258) scratch
+int launch_grad_scale(const float* d_eps, int64_t n, float* scale_out, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// LoRA skinny kernels (rank r <= 32)
+// ---------------------------------------------------------------------------------------------------------------
+// xa[M, r] = X[M, K] (T, row stride ldx) * A[r, K]^T (f32)                       (lora_down / dXA = dY * up)
+int launch_lora_down(int dtype, const void* X, int64_t ldx, const float* A, int64_t lda_r, int64_t lda_k, float* xa,
+                     int64_t ld_xa, int M, int K, int r, hipStream_t stream);
+// dW[r, K] (+)= alpha * P[M, r]^T (f32) * X[M, K] (T)     -- weight-gradient reduction over M
+//   out index (q, k) -> dW[q*so_r + k*so_k]
+int launch_lora_wgrad(int dtype, const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r,
+                      int64_t so_k, int M, int K, int r, float alpha, const float* alpha_dev, float* scratch,
+                      hipStream_t stream);
+size_t lora_wgrad_scratch_floats(int M, int K, int r);
+
+// ---------------------------------------------------------------------------------------------------------------
+// slider-step elementwise ops (K9-K11)
+// ---------------------------------------------------------------------------------------------------------------
+int launch_cfg_combine(const float* eps2 /*[2B,...]*/, float* out /*[B,...]*/, int64_t n_half, float g,
+                       hipStream_t stream);
+// loss = mean((target - (neutral + sign*eta*(positive - negative)))^2) ; dtarget = 2*(target-goal)/n
+int launch_slider_loss(const float* target, const float* positive, const float* neutral, const float* negative,
+                       float sign_eta, int64_t n, float* loss_out, float* dtarget, float* scratch,
+                       hipStream_t stream);
+int launch_axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t stream);  // y = a*x + b*y
+// global-norm clip (max_norm<=0: none) + AdamW on flat f32 buffers; state m,v; step>=1
+int launch_clip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, float max_norm, float* scratch /*>= 1024+2 floats*/,
+                      hipStream_t stream);
+// DDIM (eta=0): x = c0*x + c1*eps ; Euler-a: x = x + eps*dt + noise*sigma_up
+int launch_sched_affine(float* x, const float* eps, const float* noise, float c_x, float c_eps, float c_noise,
+                        int64_t n, hipStream_t stream);
+
+}  // namespace smi

@@ -1,0 +1,179 @@
+// Rank-r (r <= 32) LoRA kernels: the two skinny products that cannot ride inside the big MFMA GEMM.
+//
+//  lora_down : xa[M, r] = X[M, K] * A[r, K]^T          one wave per row, K split over the lanes in 16-byte
+//              vectors, r accumulators per lane, butterfly (wavefront shuffle) reduction.  Also used for
+//              dXA = dY * up (A given with strides).  HBM-bound: reads X once.
+//  lora_wgrad: dW[r, K] += alpha * P[M, r]^T * X[M, K]   weight-gradient reduction over the 4*N tokens:
+//              each thread owns one 16-byte column vector of X and r x 8 f32 accumulators, workgroups split M;
+//              per-workgroup partials are combined through LDS and a second fixed-order pass (deterministic).
+// The up-projection delta itself (xa * up^T) is fused into the GEMM epilogue (gemm.hip).
+#include "kernels.h"
+
+namespace smi {
+namespace {
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void lora_down_kernel(const T* __restrict__ X, int64_t ldx,
+                                                        const float* __restrict__ A, int64_t sa_r, int64_t sa_k,
+                                                        float* __restrict__ xa, int64_t ld_xa, int M, int K,
+                                                        int r) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float acc[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) acc[q] = 0.f;
+  const int nvec = K / 8;
+  for (int v = lane; v < nvec; v += 64) {
+    Pack8<T> xv;
+    xv.u = *reinterpret_cast<const u32x4*>(X + (int64_t)row * ldx + v * 8);
+    float xf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xf[e] = to_f(xv.e[e]);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      if (q < r) {
+        const float* a = A + q * sa_r + (int64_t)v * 8 * sa_k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[q] += xf[e] * a[e * sa_k];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const float s = wave_sum(acc[q]);
+    if (lane == 0 && q < r) xa[(int64_t)row * ld_xa + q] = s;
+  }
+}
+
+constexpr int WG_ROWS = 512;  // rows of M per workgroup in the weight-gradient reduction
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(const float* __restrict__ P, int64_t ldp,
+                                                                 const T* __restrict__ X, int64_t ldx,
+                                                                 float* __restrict__ partial, int M, int K, int r) {
+  extern __shared__ float red[];  // [rpar][R][8 * ncols_in_block]
+  const int cols8 = K / 8;
+  const int colblk = blockIdx.y;  // blocks of up to 256 column vectors
+  const int ncb = min(256, cols8 - colblk * 256);
+  const int rpar = 256 / ncb >= 1 ? 256 / ncb : 1;
+  const int tid = threadIdx.x;
+  const int rsub = tid / ncb;
+  const int cl = tid - rsub * ncb;
+  const bool active = rsub < rpar;
+  const int col = colblk * 256 + cl;
+  const int row0 = blockIdx.x * WG_ROWS;
+  const int row1 = min(M, row0 + WG_ROWS);
+  float acc[R][8];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+  if (active) {
+    for (int m = row0 + rsub; m < row1; m += rpar) {
+      Pack8<T> xv;
+      xv.u = *reinterpret_cast<const u32x4*>(X + (int64_t)m * ldx + col * 8);
+      const float* pr = P + (int64_t)m * ldp;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        if (q < r) {
+          const float pq = pr[q];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[q][e] += pq * to_f(xv.e[e]);
+        }
+      }
+    }
+  }
+  // combine the rpar row-slices through LDS in a fixed order
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (q < r) {  // r is block-uniform: the barriers below are reached by every thread or by none
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(rsub * ncb + cl) * 8 + e] = acc[q][e];
+      }
+      __syncthreads();
+      if (tid < ncb) {
+        float* out = partial + ((int64_t)blockIdx.x * r + q) * K + (colblk * 256 + tid) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float s = 0.f;
+          for (int rs = 0; rs < rpar; ++rs) s += red[(rs * ncb + tid) * 8 + e];
+          out[e] = s;
+        }
+      }
+    }
+  }
+}
+
+// dW[q*so_r + k*so_k] += alpha * alpha_dev * sum_s partial[s][q][k]
+__global__ void lora_wgrad_final_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ dW,
+                                        int64_t so_r, int64_t so_k, int K, int r, float alpha,
+                                        const float* __restrict__ alpha_dev) {
+  const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
+  const int64_t total = (int64_t)r * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i / K);
+    const int k = (int)(i - (int64_t)q * K);
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[((int64_t)sp * r + q) * K + k];
+    dW[q * so_r + k * so_k] += a * s;
+  }
+}
+
+template <typename T>
+int down_t(const void* X, int64_t ldx, const float* A, int64_t sr, int64_t sk, float* xa, int64_t ld_xa, int M, int K,
+           int r, hipStream_t st) {
+  const int grid = cdiv(M, 4);
+#define L(RR) hipLaunchKernelGGL((lora_down_kernel<T, RR>), dim3(grid), dim3(256), 0, st, (const T*)X, ldx, A, sr, sk, xa, ld_xa, M, K, r)
+  if (r <= 4) L(4);
+  else if (r <= 8) L(8);
+  else if (r <= 16) L(16);
+  else L(32);
+#undef L
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int wgrad_t(const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r, int64_t so_k, int M, int K, int r,
+            float alpha, const float* alpha_dev, float* scratch, hipStream_t st) {
+  const int nsplit = cdiv(M, WG_ROWS);
+  const int cols8 = K / 8;
+  dim3 grid(nsplit, cdiv(cols8, 256));
+  const size_t sm = 256 * 8 * sizeof(float);
+#define L(RR) hipLaunchKernelGGL((lora_wgrad_partial_kernel<T, RR>), grid, dim3(256), sm, st, P, ldp, (const T*)X, ldx, scratch, M, K, r)
+  if (r <= 4) L(4);
+  else if (r <= 8) L(8);
+  else if (r <= 16) L(16);
+  else L(32);
+#undef L
+  const int64_t total = (int64_t)r * K;
+  hipLaunchKernelGGL(lora_wgrad_final_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, scratch, nsplit, dW,
+                     so_r, so_k, K, r, alpha, alpha_dev);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int launch_lora_down(int dtype, const void* X, int64_t ldx, const float* A, int64_t lda_r, int64_t lda_k, float* xa,
+                     int64_t ld_xa, int M, int K, int r, hipStream_t stream) {
+  SMI_CHECK(r >= 1 && r <= 32 && K % 8 == 0 && ldx % 8 == 0, "lora_down: r=%d K=%d ldx=%lld", r, K, (long long)ldx);
+  return dtype == DT_F16 ? down_t<f16>(X, ldx, A, lda_r, lda_k, xa, ld_xa, M, K, r, stream)
+                         : down_t<bf16>(X, ldx, A, lda_r, lda_k, xa, ld_xa, M, K, r, stream);
+}
+
+// scratch: cdiv(M, 512) * r * K floats
+size_t lora_wgrad_scratch_floats(int M, int K, int r) { return (size_t)cdiv(M, WG_ROWS) * r * K; }
+
+int launch_lora_wgrad(int dtype, const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r,
+                      int64_t so_k, int M, int K, int r, float alpha, const float* alpha_dev, float* scratch,
+                      hipStream_t stream) {
+  SMI_CHECK(r >= 1 && r <= 32 && K % 8 == 0 && ldx % 8 == 0, "lora_wgrad: r=%d K=%d", r, K);
+  return dtype == DT_F16 ? wgrad_t<f16>(P, ldp, X, ldx, dW, so_r, so_k, M, K, r, alpha, alpha_dev, scratch, stream)
+                         : wgrad_t<bf16>(P, ldp, X, ldx, dW, so_r, so_k, M, K, r, alpha, alpha_dev, scratch, stream);
+}
+
+}  // namespace smi

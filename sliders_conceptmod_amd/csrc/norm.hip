@@ -1,0 +1,429 @@
+// GroupNorm (+SiLU) and LayerNorm, forward and activation-gradient, on token-major [N, HW, C] tensors.
+// HBM-bound: every pass reads/writes each element once with 16-byte lanes; statistics are two-stage and
+// deterministic (per-chunk partials reduced in a fixed order -- no float atomics).
+//
+// GroupNorm forward:  partial(sum, sumsq per (n, chunk, g)) -> finalize (mean, rstd, per-(n,c) affine a,b)
+//                     -> apply  y = silu?(x*a + b)
+// GroupNorm backward: z = x*a+b, dz = dy*silu'(z);  S1 = sum dz*gamma, S2 = sum dz*(z-beta)  per (n,g)
+//                     dx = a*dz + c2*x + c3   with  c2 = -r^2*S2/cnt,  c3 = -r*S1/cnt - c2*mu
+#include "kernels.h"
+
+namespace smi {
+namespace {
+
+constexpr int GN_ROWS_PER_CHUNK = 256;
+
+struct GnGeom {
+  int cols8;  // C / 8
+  int ncol;   // column vectors per thread (ceil(cols8 / 256))
+  int rpar;   // rows processed in parallel by one block
+};
+__host__ __device__ inline GnGeom gn_geom(int C) {
+  GnGeom g;
+  g.cols8 = C / 8;
+  g.ncol = (g.cols8 + 255) / 256;
+  g.rpar = g.cols8 >= 256 ? 1 : 256 / g.cols8;
+  return g;
+}
+
+// MODE 0: forward stats (sum x, sum x^2).  MODE 1: backward stats (S1, S2), SILU selects dz = dy*silu'(z)
+template <typename T, int MODE, bool SILU>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                         const float* __restrict__ ab, float* __restrict__ partial,
+                                                         int Nb, int HW, int C, int G, int nchunk) {
+  extern __shared__ float red[];  // [rpar][C][2]
+  const GnGeom gg = gn_geom(C);
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int rsub = gg.cols8 >= 256 ? 0 : tid / gg.cols8;
+  const int col_base = gg.cols8 >= 256 ? tid : tid - rsub * gg.cols8;
+  const bool active = rsub < gg.rpar;
+  const int row0 = chunk * GN_ROWS_PER_CHUNK;
+  const int row1 = min(HW, row0 + GN_ROWS_PER_CHUNK);
+  const float* an = ab + (int64_t)n * C;
+  const float* bn = ab + ((int64_t)Nb + n) * C;
+
+  for (int j = 0; j < gg.ncol; ++j) {
+    const int col = col_base + 256 * j;
+    const bool cok = active && col < gg.cols8;
+    float s0[8], s1[8], av[8], bv[8], gv[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    if (cok && MODE == 1) {
+      Pack8<T> g8, b8;
+      g8.u = *reinterpret_cast<const u32x4*>(gamma + col * 8);
+      b8.u = *reinterpret_cast<const u32x4*>(beta + col * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        av[e] = an[col * 8 + e];
+        bv[e] = bn[col * 8 + e];
+        gv[e] = to_f(g8.e[e]);
+        be[e] = to_f(b8.e[e]);
+      }
+    }
+    if (cok) {
+      for (int r = row0 + rsub; r < row1; r += gg.rpar) {
+        const int64_t off = ((int64_t)n * HW + r) * C + col * 8;
+        Pack8<T> xv;
+        xv.u = *reinterpret_cast<const u32x4*>(x + off);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = to_f(xv.e[e]);
+            s0[e] += v;
+            s1[e] += v * v;
+          }
+        } else {
+          Pack8<T> dv;
+          dv.u = *reinterpret_cast<const u32x4*>(dy + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float z = to_f(xv.e[e]) * av[e] + bv[e];
+            float dz = to_f(dv.e[e]);
+            if (SILU) dz *= dsilu_f(z);
+            s0[e] += dz * gv[e];
+            s1[e] += dz * (z - be[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[((int64_t)rsub * C + col * 8 + e) * 2 + 0] = s0[e];
+        red[((int64_t)rsub * C + col * 8 + e) * 2 + 1] = s1[e];
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int rs = 0; rs < gg.rpar; ++rs)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        a0 += red[((int64_t)rs * C + c) * 2 + 0];
+        a1 += red[((int64_t)rs * C + c) * 2 + 1];
+      }
+    float* out = partial + (((int64_t)n * nchunk + chunk) * G + g) * 2;
+    out[0] = a0;
+    out[1] = a1;
+  }
+}
+
+// forward finalize: mean/rstd per (n,g) and per-(n,c) affine
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(const float* __restrict__ partial,
+                                                              const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                              float* __restrict__ ab, float* __restrict__ mean_rstd,
+                                                              int Nb, int HW, int C, int G, int nchunk, float eps) {
+  extern __shared__ float st[];  // [G][2]
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float s = 0.f, sq = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* p = partial + (((int64_t)n * nchunk + ch) * G + g) * 2;
+      s += p[0];
+      sq += p[1];
+    }
+    const float cnt = (float)HW * (float)cpg;
+    const float mean = s / cnt;
+    const float var = fmaxf(sq / cnt - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    st[g * 2] = mean;
+    st[g * 2 + 1] = rstd;
+    mean_rstd[((int64_t)n * G + g) * 2] = mean;
+    mean_rstd[((int64_t)n * G + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float a = st[g * 2 + 1] * to_f(gamma[c]);
+    ab[(int64_t)n * C + c] = a;
+    ab[((int64_t)Nb + n) * C + c] = to_f(beta[c]) - st[g * 2] * a;
+  }
+}
+
+// backward finalize: per-(n,c) coefficients c2, c3 (stored in cd[2][Nb][C])
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(const float* __restrict__ partial,
+                                                              const float* __restrict__ mean_rstd,
+                                                              float* __restrict__ cd, int Nb, int HW, int C, int G,
+                                                              int nchunk) {
+  extern __shared__ float st[];  // [G][2] = c2, c3
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* p = partial + (((int64_t)n * nchunk + ch) * G + g) * 2;
+      s1 += p[0];
+      s2 += p[1];
+    }
+    const float cnt = (float)HW * (float)cpg;
+    const float mu = mean_rstd[((int64_t)n * G + g) * 2];
+    const float r = mean_rstd[((int64_t)n * G + g) * 2 + 1];
+    const float c2 = -r * r * s2 / cnt;
+    st[g * 2] = c2;
+    st[g * 2 + 1] = -r * s1 / cnt - c2 * mu;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    cd[(int64_t)n * C + c] = st[g * 2];
+    cd[((int64_t)Nb + n) * C + c] = st[g * 2 + 1];
+  }
+}
+
+// MODE 0: y = silu?(x*a+b).   MODE 1: dx = a*dz + c2*x + c3
+template <typename T, int MODE, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const float* __restrict__ ab, const float* __restrict__ cd,
+                                                       const T* add, T* out, int Nb, int HW, int C) {
+  const int cols8 = C / 8;
+  const int64_t total = (int64_t)Nb * HW * cols8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % cols8);
+    const int64_t row = i / cols8;
+    const int n = (int)(row / HW);
+    const float* a = ab + (int64_t)n * C + col * 8;
+    const float* b = ab + ((int64_t)Nb + n) * C + col * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(b), b1 = *reinterpret_cast<const f32x4*>(b + 4);
+    Pack8<T> xv, o;
+    xv.u = *reinterpret_cast<const u32x4*>(x + row * C + col * 8);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float z = to_f(xv.e[e]) * (e < 4 ? a0[e & 3] : a1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
+        if (SILU) z = silu_f(z);
+        o.e[e] = from_f<T>(z);
+      }
+    } else {
+      const float* c2 = cd + (int64_t)n * C + col * 8;
+      const float* c3 = cd + ((int64_t)Nb + n) * C + col * 8;
+      Pack8<T> dv, ad;
+      dv.u = *reinterpret_cast<const u32x4*>(dy + row * C + col * 8);
+      if (add) ad.u = *reinterpret_cast<const u32x4*>(add + row * C + col * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float av = (e < 4 ? a0[e & 3] : a1[e & 3]);
+        const float xe = to_f(xv.e[e]);
+        float dz = to_f(dv.e[e]);
+        if (SILU) dz *= dsilu_f(xe * av + (e < 4 ? b0[e & 3] : b1[e & 3]));
+        o.e[e] = from_f<T>(av * dz + c2[e] * xe + c3[e] + (add ? to_f(ad.e[e]) : 0.f));
+      }
+    }
+    *reinterpret_cast<u32x4*>(out + row * C + col * 8) = o.u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, C <= 8*64*LN_MAXV
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;  // C <= 2048
+
+template <typename T, int MODE>  // 0 fwd, 1 bwd
+__global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                 const T* __restrict__ gamma, const T* beta, T* out,
+                                                 float* __restrict__ mean_rstd, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = C / 8;
+  float xv[LN_MAXV][8];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int v = lane + 64 * j;
+    if (v < nvec) {
+      Pack8<T> t;
+      t.u = *reinterpret_cast<const u32x4*>(x + (int64_t)row * C + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[j][e] = to_f(t.e[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[j][e] = 0.f;
+    }
+  }
+  float mean, rstd;
+  if (MODE == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += xv[j][e];
+    mean = wave_sum(s) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = xv[j][e] - mean;
+          sq += d * d;
+        }
+      }
+    }
+    rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    if (lane == 0) {
+      mean_rstd[(int64_t)row * 2] = mean;
+      mean_rstd[(int64_t)row * 2 + 1] = rstd;
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        Pack8<T> g8, b8, o;
+        g8.u = *reinterpret_cast<const u32x4*>(gamma + v * 8);
+        b8.u = *reinterpret_cast<const u32x4*>(beta + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>((xv[j][e] - mean) * rstd * to_f(g8.e[e]) + to_f(b8.e[e]));
+        *reinterpret_cast<u32x4*>(out + (int64_t)row * C + v * 8) = o.u;
+      }
+    }
+  } else {
+    mean = mean_rstd[(int64_t)row * 2];
+    rstd = mean_rstd[(int64_t)row * 2 + 1];
+    float dg[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        Pack8<T> g8, d8;
+        g8.u = *reinterpret_cast<const u32x4*>(gamma + v * 8);
+        d8.u = *reinterpret_cast<const u32x4*>(dy + (int64_t)row * C + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xv[j][e] = (xv[j][e] - mean) * rstd;  // xhat
+          dg[j][e] = to_f(d8.e[e]) * to_f(g8.e[e]);
+          s1 += dg[j][e];
+          s2 += dg[j][e] * xv[j][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[j][e] = 0.f;
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        Pack8<T> o, ad;
+        if (beta) ad.u = *reinterpret_cast<const u32x4*>(beta + (int64_t)row * C + v * 8);  // bwd: beta = `add`
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o.e[e] = from_f<T>(rstd * (dg[j][e] - s1 - xv[j][e] * s2) + (beta ? to_f(ad.e[e]) : 0.f));
+        *reinterpret_cast<u32x4*>(out + (int64_t)row * C + v * 8) = o.u;
+      }
+    }
+  }
+}
+
+inline int ew_grid(int64_t n_threads) {
+  int64_t g = (n_threads + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+template <typename T>
+int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* ab, float* mean_rstd, float* partial,
+             int Nb, int HW, int C, int G, float eps, int silu, hipStream_t st) {
+  const int nchunk = gn_num_chunks(HW);
+  const GnGeom gg = gn_geom(C);
+  const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
+  hipLaunchKernelGGL((gn_partial_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x, nullptr,
+                     nullptr, nullptr, ab, partial, Nb, HW, C, G, nchunk);
+  hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(Nb), dim3(256), G * 2 * sizeof(float), st, partial,
+                     (const T*)gamma, (const T*)beta, ab, mean_rstd, Nb, HW, C, G, nchunk, eps);
+  const int grid = ew_grid((int64_t)Nb * HW * (C / 8));
+  if (silu)
+    hipLaunchKernelGGL((gn_apply_kernel<T, 0, true>), dim3(grid), dim3(256), 0, st, (const T*)x, nullptr, ab, nullptr,
+                       nullptr, (T*)y, Nb, HW, C);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<T, 0, false>), dim3(grid), dim3(256), 0, st, (const T*)x, nullptr, ab,
+                       nullptr, nullptr, (T*)y, Nb, HW, C);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta, const float* ab,
+             const float* mean_rstd, const void* add, void* dx, float* partial, float* cd, int Nb, int HW, int C,
+             int G, int silu, hipStream_t st) {
+  const int nchunk = gn_num_chunks(HW);
+  const GnGeom gg = gn_geom(C);
+  const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
+  if (silu)
+    hipLaunchKernelGGL((gn_partial_kernel<T, 1, true>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x,
+                       (const T*)dy, (const T*)gamma, (const T*)beta, ab, partial, Nb, HW, C, G, nchunk);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<T, 1, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x,
+                       (const T*)dy, (const T*)gamma, (const T*)beta, ab, partial, Nb, HW, C, G, nchunk);
+  hipLaunchKernelGGL(gn_finalize_bwd_kernel<T>, dim3(Nb), dim3(256), G * 2 * sizeof(float), st, partial, mean_rstd, cd,
+                     Nb, HW, C, G, nchunk);
+  const int grid = ew_grid((int64_t)Nb * HW * (C / 8));
+  if (silu)
+    hipLaunchKernelGGL((gn_apply_kernel<T, 1, true>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, ab, cd,
+                       (const T*)add, (T*)dx, Nb, HW, C);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<T, 1, false>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, ab,
+                       cd, (const T*)add, (T*)dx, Nb, HW, C);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int gn_num_chunks(int HW) { return (HW + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK; }
+
+int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* ab,
+                         float* mean_rstd, float* partial, int Nb, int HW, int C, int G, float eps, int silu,
+                         hipStream_t stream) {
+  SMI_CHECK(C % 8 == 0 && C % G == 0, "groupnorm: C=%d must be a multiple of 8 and of G=%d", C, G);
+  SMI_CHECK((size_t)gn_geom(C).rpar * C * 8 <= 65536, "groupnorm: C=%d too large for the LDS reduction", C);
+  return dtype == DT_F16 ? gn_fwd_t<f16>(x, gamma, beta, y, ab, mean_rstd, partial, Nb, HW, C, G, eps, silu, stream)
+                         : gn_fwd_t<bf16>(x, gamma, beta, y, ab, mean_rstd, partial, Nb, HW, C, G, eps, silu, stream);
+}
+
+// `partial` must hold Nb*nchunk*G*2 floats followed by 2*Nb*C floats (the c2/c3 coefficient arrays)
+int launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const void* beta,
+                         const float* ab, const float* mean_rstd, const void* add, void* dx, float* partial, int Nb,
+                         int HW, int C, int G, int silu, hipStream_t stream) {
+  SMI_CHECK(C % 8 == 0 && C % G == 0, "groupnorm bwd: C=%d G=%d", C, G);
+  float* cd = partial + (size_t)Nb * gn_num_chunks(HW) * G * 2;
+  return dtype == DT_F16
+             ? gn_bwd_t<f16>(x, dy, gamma, beta, ab, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream)
+             : gn_bwd_t<bf16>(x, dy, gamma, beta, ab, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream);
+}
+
+int launch_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean_rstd,
+                         int M, int C, float eps, hipStream_t stream) {
+  SMI_CHECK(C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "layernorm: C=%d unsupported", C);
+  const int grid = cdiv(M, 4);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL((ln_kernel<f16, 0>), dim3(grid), dim3(256), 0, stream, (const f16*)x, nullptr,
+                       (const f16*)gamma, (const f16*)beta, (f16*)y, mean_rstd, M, C, eps);
+  else
+    hipLaunchKernelGGL((ln_kernel<bf16, 0>), dim3(grid), dim3(256), 0, stream, (const bf16*)x, nullptr,
+                       (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean_rstd, M, C, eps);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_layernorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const float* mean_rstd,
+                         const void* add, void* dx, int M, int C, hipStream_t stream) {
+  SMI_CHECK(C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "layernorm: C=%d unsupported", C);
+  const int grid = cdiv(M, 4);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL((ln_kernel<f16, 1>), dim3(grid), dim3(256), 0, stream, (const f16*)x, (const f16*)dy,
+                       (const f16*)gamma, (const f16*)add, (f16*)dx, const_cast<float*>(mean_rstd), M, C, 0.f);
+  else
+    hipLaunchKernelGGL((ln_kernel<bf16, 1>), dim3(grid), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy,
+                       (const bf16*)gamma, (const bf16*)add, (bf16*)dx, const_cast<float*>(mean_rstd), M, C, 0.f);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace smi

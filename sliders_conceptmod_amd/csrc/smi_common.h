@@ -1,0 +1,131 @@
+// Common device/host helpers for the gfx950 (MI355X, CDNA4) slider-trainer kernels.
+// Everything here is written for wave64 / MFMA / buffer addressing on gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace smi {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+enum DType : int { DT_F16 = 0, DT_BF16 = 1 };
+
+// ---------------------------------------------------------------------------------------------------
+// per-dtype traits: 8-wide fragment type and the two MFMA shapes used (16x16x32 for GEMM/conv,
+// 32x32x16 for attention).  Operand maps (cdna_hip_programming.md section 3):
+//   16x16x32: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], j=0..7
+//             D: col = l&15, row = 4(l>>4)+reg
+//   32x32x16: lane l holds A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]
+//             D: col = l&31, row = (reg&3) + 8(reg>>2) + 4(l>>5)
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct TT;
+template <> struct TT<f16> {
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct TT<bf16> {
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x) { return (T)x; }
+
+// 16-byte / 8-byte reinterpretation helpers
+template <typename T> union Pack8 {
+  u32x4 u;
+  typename TT<T>::v8 v;
+  T e[8];
+};
+template <typename T> union Pack4 {
+  u32x2 u;
+  typename TT<T>::v4 v;
+  T e[4];
+};
+
+// ---------------------------------------------------------------------------------------------------
+// buffer addressing: hardware range check -> out-of-range loads return 0, stores are dropped.
+// Used for conv zero padding, M/N tails, and as a guard against wild accesses.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ u32x2 buf_load8(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, u32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)byte_off, 0, 0);
+}
+static constexpr uint32_t OOB = 0xFFFFFFF0u;  // voffset that is out of range for every descriptor we build (< 4 GiB - 16)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// host side ------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define SMI_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::smi::set_error(__VA_ARGS__);    \
+      return -1;                        \
+    }                                   \
+  } while (0)
+#define SMI_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      ::smi::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return -2;                                                                       \
+    }                                                                                  \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace smi

@@ -209,6 +209,8 @@ def main():
         torch.manual_seed(1)  # LoRA down init uses the global RNG (lora.py:123)
         net = ref_lora.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, target_replace=["Attention"],
                                    train_method="noxattn")
+        for l in (net.unet_loras[0], net.unet_loras[-1]):
+            tensors[f"traj/{model}/init/{l.lora_name}.lora_down.weight"] = l.lora_down.weight.detach().clone()
         keys = ["target", "positive", "neutral", "unconditional"] + (["negative"] if xl else [])
         emb, pooled = synth_embeds(cfg, keys, seed=4)
         if not xl:

@@ -1,0 +1,166 @@
+"""Host-side logic of the product package (no GPU): adaptor API, state-dict layout, C-ABI exports, workspace plan."""
+import ctypes
+import dataclasses
+import hashlib
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import sliders_conceptmod_amd.lora as L
+import sliders_conceptmod_amd.unet as PU
+from sliders_conceptmod_amd import _native, build as smi_build
+from oracle import unet_ref as OU
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFGS = {"sd1x": OU.sd1x_config, "sdxl": OU.sdxl_config, "tiny_sd1x": OU.tiny_sd1x_config,
+        "tiny_sdxl": OU.tiny_sdxl_config}
+
+
+def pcfg(ocfg):
+    return PU.UNetConfig(**dataclasses.asdict(ocfg))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    return smi_build.build()
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+def test_product_skeleton_matches_oracle_state_dict(model):
+    with torch.device("meta"):
+        a = PU.UNet2DConditionModel(pcfg(CFGS[model]()))
+        b = OU.UNet2DConditionModel(CFGS[model]())
+    sa = {k: tuple(v.shape) for k, v in a.state_dict().items()}
+    sb = {k: tuple(v.shape) for k, v in b.state_dict().items()}
+    assert list(sa.items()) == list(sb.items())
+
+
+def test_public_configs_match():
+    assert dataclasses.asdict(PU.sd1x_config()) == dataclasses.asdict(OU.sd1x_config())
+    assert dataclasses.asdict(PU.sdxl_config()) == dataclasses.asdict(OU.sdxl_config())
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+@pytest.mark.parametrize("method", ["noxattn", "innoxattn", "selfattn", "xattn", "full", "xattn-strict"])
+def test_lora_network_names_and_shapes_match_reference(goldens, model, method):
+    _, man = goldens
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(pcfg(CFGS[model]()))
+    net = L.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, train_method=method)
+    g = man["selection"][f"{model}/{method}"]
+    names = [l.lora_name for l in net.unet_loras]
+    assert len(names) == g["n_modules"]
+    assert hashlib.sha256("\n".join(names).encode()).hexdigest() == g["names_sha"]
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert hashlib.sha256(json.dumps(shapes, sort_keys=True).encode()).hexdigest() == g["shapes_sha"]
+    assert net._n_down + net._n_up == g["n_params"]
+    assert sum(p.numel() for p in net.parameters()) == g["n_params"]
+
+
+def test_bad_train_method_raises_like_reference(goldens):
+    _, man = goldens
+    assert man["bad_method_error"] == "NotImplementedError"
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(pcfg(OU.tiny_sd1x_config()))
+    with pytest.raises(NotImplementedError):
+        L.LoRANetwork(unet, train_method="bogus")
+
+
+@pytest.mark.parametrize("model", ["tiny_sd1x", "tiny_sdxl"])
+def test_lora_init_is_seed_compatible_with_reference(goldens, model):
+    t, _ = goldens
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(pcfg(CFGS[model]()))
+    torch.manual_seed(1)
+    net = L.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    sd = net.state_dict()
+    keys = [k for k in t if k.startswith(f"traj/{model}/init/")]
+    assert len(keys) == 2
+    for k in keys:
+        torch.testing.assert_close(sd[k.split("/init/")[1]], t[k], rtol=0, atol=0)
+    assert float(net.flat_up.detach().abs().max()) == 0.0
+
+
+def test_context_manager_and_slider_semantics():
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(pcfg(OU.tiny_sd1x_config()))
+    net = L.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    assert net.engine_params()[2] == 1.0  # constructor multiplier (lora.py:126)
+    with net:
+        assert all(l.multiplier == 1.0 for l in net.unet_loras)
+    assert all(l.multiplier == 0 for l in net.unet_loras)  # lora.py:299-301
+    net.set_lora_slider(-2.5)
+    with net:
+        assert net.engine_params()[2] == -2.5
+    assert net.prepare_optimizer_params()[0]["params"][0] is net.flat_down
+    assert net.unet_loras[0].scale == 0.25
+
+
+def test_save_and_strict_reload(tmp_path):
+    unet = PU.UNet2DConditionModel(pcfg(OU.tiny_sd1x_config()))
+    net = L.LoRANetwork(unet, rank=4, alpha=1.0, train_method="noxattn")
+    with torch.no_grad():
+        net.flat_up.normal_(0, 0.1)
+    for ext in (".pt", ".safetensors"):
+        f = tmp_path / f"w{ext}"
+        net.save_weights(f, dtype=torch.bfloat16)
+        if ext == ".pt":
+            sd = torch.load(f, weights_only=True)
+        else:
+            from safetensors.torch import load_file
+            sd = load_file(str(f))
+        assert all(v.dtype == torch.bfloat16 for k, v in sd.items())
+        net2 = L.LoRANetwork(unet, rank=4, alpha=1.0, train_method="noxattn")
+        net2.load_state_dict(sd)
+        torch.testing.assert_close(net2.flat_up.detach(), net.flat_up.detach().bfloat16().float())
+        bad = dict(sd)
+        bad.pop(next(iter(bad)))
+        with pytest.raises(RuntimeError):
+            net2.load_state_dict(bad)
+    net.to(dtype=torch.bfloat16)  # reference does .to(device, dtype=weight_dtype); master weights stay fp32
+    assert net.flat_down.dtype == torch.float32
+
+
+def test_unet_without_gpu_fails_loudly():
+    unet = PU.UNet2DConditionModel(pcfg(OU.tiny_sd1x_config())).half()
+    with pytest.raises(_native.SmiError):
+        unet(torch.zeros(2, 4, 8, 8), 10, torch.zeros(2, 77, 64))
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    hdr = open(os.path.join(ROOT, "include", "smi.h")).read()
+    declared = set(re.findall(r"\b(smi_[a-z0-9_]+)\s*\(", hdr)) - {"smi_engine"}
+    lib = ctypes.CDLL(libpath)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in include/smi.h but not exported"
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+
+
+@pytest.mark.parametrize("model,batch,hw", [("tiny_sd1x", 2, 16), ("tiny_sdxl", 2, 16), ("sd1x", 8, 64),
+                                             ("sdxl", 4, 128)])
+def test_workspace_plan_dry_run(libpath, model, batch, hw):
+    """smi_workspace_bytes runs the engine's forward+backward graph in dry mode (no GPU needed)."""
+    cfg = pcfg(CFGS[model]())
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(cfg)
+    net = L.LoRANetwork(unet, rank=4, alpha=1.0, train_method="noxattn")
+    cc = _native.make_config(cfg, torch.float16)
+    with_lora = _native.workspace_bytes(cc, net.engine_sites(), batch, hw, hw, 77)
+    without = _native.workspace_bytes(cc, [], batch, hw, hw, 77)
+    assert with_lora > without > 0
+    nparam = sum(p.numel() for p in unet.parameters())
+    assert without > nparam * 2  # at least the transposed copies
+    if model == "sdxl":
+        assert with_lora < 200e9, f"SD-XL 1024^2 batch 4 plan = {with_lora/1e9:.1f} GB must fit in 288 GB HBM"
+    print(f"{model}: workspace {with_lora/1e9:.2f} GB (no-LoRA {without/1e9:.2f} GB)")
+
+
+def test_engine_rejects_unsupported_lora_target(libpath):
+    cfg = pcfg(OU.tiny_sd1x_config())
+    cc = _native.make_config(cfg, torch.float16)
+    with pytest.raises(_native.SmiError, match="not an attention projection"):
+        _native.workspace_bytes(cc, [{"target": "down_blocks.0.resnets.0.time_emb_proj", "off_down": 0, "off_up": 0,
+                                      "rank": 4, "scale": 0.25}], 2, 16, 16, 77)
