@@ -145,7 +145,7 @@ class LoRANetwork(nn.Module):
                 torch.empty(lora.out_dim, lora.lora_dim).uniform_()
                 nn.init.kaiming_uniform_(lora.lora_down.weight, a=1)
         # "apply_to": register with the engine-backed UNet instead of patching module forwards (lora.py:129-132)
-        unet._lora_network = self
+        unet.__dict__["_lora_network"] = self  # plain attribute: must not become a registered child module
         self._n_down, self._n_up = n_down, n_up
 
     # ---- engine side ---------------------------------------------------------------------------------------------

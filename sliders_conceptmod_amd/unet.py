@@ -201,8 +201,8 @@ class _UNetFn(torch.autograd.Function):
     """Autograd bookkeeping only: forward and backward are single calls into the HIP engine."""
 
     @staticmethod
-    def forward(ctx, unet, engine, sample, timestep, ehs, text_embeds, time_ids, flat_down, flat_up, multiplier):
-        save = torch.is_grad_enabled() and multiplier != 0 and flat_down is not None and flat_down.requires_grad
+    def forward(ctx, save, engine, sample, timestep, ehs, text_embeds, time_ids, flat_down, flat_up, multiplier):
+        # `save` is decided by the caller: grad mode is always off inside Function.forward
         eps = engine.forward(sample, timestep, ehs, text_embeds, time_ids, flat_down, flat_up, multiplier, save)
         ctx.engine = engine if save else None
         ctx.keep = (sample, ehs, text_embeds, time_ids, flat_down, flat_up)  # borrowed by the engine until backward
@@ -260,7 +260,7 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
         self._engine: Optional[_native.Engine] = None
         self._engine_key = None
-        self._lora_network = None  # set by LoRANetwork (sliders_conceptmod_amd.lora)
+        self.__dict__["_lora_network"] = None  # set by LoRANetwork (sliders_conceptmod_amd.lora); not a child module
 
     # ---- reference call surface -------------------------------------------------------------------------------
     def enable_xformers_memory_efficient_attention(self):
@@ -309,7 +309,8 @@ class UNet2DConditionModel(nn.Module):
         mult = 0.0
         if net is not None:
             flat_down, flat_up, mult = net.engine_params()
-        eps = _UNetFn.apply(self, eng, sample.float().contiguous(), t, ehs, text_embeds, time_ids, flat_down, flat_up,
+        save = bool(torch.is_grad_enabled() and mult != 0 and flat_down is not None and flat_down.requires_grad)
+        eps = _UNetFn.apply(save, eng, sample.float().contiguous(), t, ehs, text_embeds, time_ids, flat_down, flat_up,
                             float(mult))
         return UNetOutput(eps)
 

@@ -1,0 +1,169 @@
+"""End-to-end parity of the HIP engine (through the product UNet2DConditionModel / LoRANetwork and the C ABI) against
+the CPU oracle (oracle/unet_ref.py + oracle/slider_ref.py) on the same seeded inputs.
+
+Tolerances are relative L2 norms, written at each assert.  The engine stores activations in fp16/bf16 (fp32
+accumulate), so its distance to the pure-fp32 oracle is storage-rounding noise accumulated over ~100 layers:
+measured ~1e-3 (fp16) and ~8e-3 (bf16) on these nets.  That noise level is calibrated independently of the engine:
+the oracle itself, run with `storage_dtype` (rounding at exactly the points where the engine writes HBM), lands at
+the same distance from fp32 -- the engine must not be noisier than 1.5x that.  (Rounding decisions of two runs
+decorrelate after a few layers, so engine-vs-rounded-oracle is ~sqrt(2) x that distance, not ~0.)"""
+import dataclasses
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import slider_ref as R
+from oracle import unet_ref as OU
+
+CFGS = {"tiny_sd1x": OU.tiny_sd1x_config, "tiny_sdxl": OU.tiny_sdxl_config}
+LOOSE = {torch.float16: 3e-3, torch.bfloat16: 2.5e-2}   # vs pure fp32 oracle (measured ~1e-3 / ~8e-3)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def build_pair(model, dtype, method="noxattn", rank=4, lora_seed=2, ocfg=None):
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.unet as PU
+    ocfg = ocfg or CFGS[model]()
+    ou = OU.init_synthetic_(OU.UNet2DConditionModel(ocfg), seed=0).requires_grad_(False).eval()
+    pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(ocfg)))
+    pu.load_state_dict(ou.state_dict())
+    pu = pu.to("cuda", dtype).requires_grad_(False).eval()
+    torch.manual_seed(1)
+    onet = R.LoRANetworkRef(ou, rank, 1.0, 1.0, method)
+    torch.manual_seed(1)
+    pnet = L.LoRANetwork(pu, rank=rank, multiplier=1.0, alpha=1.0, train_method=method)
+    g = torch.Generator().manual_seed(lora_seed)
+    with torch.no_grad():
+        for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+            assert lo.lora_name == lp.lora_name
+            w = torch.randn(lo.lora_up.weight.shape, generator=g) * 0.05
+            lo.lora_up.weight.copy_(w)
+            lp.lora_up.weight.copy_(w)
+            torch.testing.assert_close(lp.lora_down.weight, lo.lora_down.weight, rtol=0, atol=0)
+    pnet.to("cuda")
+    return ocfg, ou, onet, pu, pnet
+
+
+def inputs(ocfg, n, hw, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 4, hw, hw, generator=g)
+    ctx = torch.randn(n, 77, ocfg.cross_attention_dim, generator=g)
+    add = None
+    if ocfg.addition_embed_type == "text_time":
+        pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
+        add = {"text_embeds": torch.randn(n, pdim, generator=g),
+               "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * n)}
+    return x, ctx, add
+
+
+def cuda_add(add):
+    return None if add is None else {k: v.cuda() for k, v in add.items()}
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_forward_parity_lora_off_and_on(model, dtype):
+    ocfg, ou, onet, pu, pnet = build_pair(model, dtype)
+    x, ctx, add = inputs(ocfg, 2, 16)
+    for t in (1.0, 499.0, 981.0):
+        for on in (False, True):
+            if on:
+                onet.__enter__(), pnet.__enter__()
+            else:
+                onet.__exit__(None, None, None), pnet.__exit__(None, None, None)
+            with torch.no_grad():
+                got = pu(x.cuda(), t, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+                ou.storage_dtype = None
+                ref32 = ou(x, t, ctx, add).sample
+                ou.storage_dtype = dtype
+                refq = ou(x, t, ctx, add).sample
+                ou.storage_dtype = None
+            assert got.dtype == torch.float32 and got.shape == ref32.shape
+            e_eng, e_q, e_x = rel(got, ref32), rel(refq, ref32), rel(got, refq)
+            print(f"{model} {dtype} t={t} lora={on}: engine-fp32 {e_eng:.2e}  rounded_oracle-fp32 {e_q:.2e}  "
+                  f"engine-rounded_oracle {e_x:.2e}")
+            assert e_eng < LOOSE[dtype], f"{model} t={t} lora={on}: vs fp32 oracle {e_eng:.2e}"
+            assert e_eng < 1.5 * e_q + 1e-4, f"engine noisier than its storage rounding explains: {e_eng:.2e} vs {e_q:.2e}"
+            assert e_x < 2.0 * e_q + 1e-4
+    # LoRA must actually change the output (guards against a silently ignored adaptor)
+    assert rel(got, pu(x.cuda(), 981.0, encoder_hidden_states=ctx.cuda(),
+                       added_cond_kwargs=cuda_add(add)).sample) == 0.0
+    pnet.__exit__(None, None, None)
+    off = pu(x.cuda(), 981.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+    assert rel(got, off) > 1e-3
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("method", ["noxattn", "full", "xattn"])
+def test_lora_gradients_match_oracle(model, dtype, method):
+    ocfg, ou, onet, pu, pnet = build_pair(model, dtype, method=method)
+    x, ctx, add = inputs(ocfg, 2, 16)
+    g = torch.Generator().manual_seed(9)
+    gy = torch.randn(2, 4, 16, 16, generator=g) * 1e-4  # the size of d(MSE)/d(eps) at real shapes: exercises the loss scale
+    with onet:
+        ref = ou(x, 499.0, ctx, add).sample
+    (ref * gy).sum().backward()
+    with pnet:
+        got = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+    assert got.requires_grad
+    (got * gy.cuda()).sum().backward()
+    assert pnet.flat_down.grad is not None and pnet.flat_up.grad is not None
+    sd_g = {}
+    for l in pnet.unet_loras:
+        n_d, n_u = l.lora_dim * l.in_dim, l.lora_dim * l.out_dim
+        sd_g[l.lora_name] = (pnet.flat_down.grad[l.off_down:l.off_down + n_d].view(l.lora_dim, l.in_dim),
+                             pnet.flat_up.grad[l.off_up:l.off_up + n_u].view(l.out_dim, l.lora_dim))
+    tol = 2.5e-2 if dtype == torch.float16 else 1.2e-1  # per-module gradient, 16-bit activation gradients
+    worst = 0.0
+    tot_num = tot_den = 0.0
+    for lo in onet.unet_loras:
+        gd, gu = sd_g[lo.lora_name]
+        for a, b, what in ((gd, lo.lora_down.weight.grad, "down"), (gu, lo.lora_up.weight.grad, "up")):
+            assert b is not None and b.abs().max() > 0, f"oracle grad missing for {lo.lora_name}.{what}"
+            r = rel(a, b)
+            worst = max(worst, r)
+            tot_num += (a.detach().cpu() - b).norm().item() ** 2
+            tot_den += b.norm().item() ** 2
+            assert r < tol, f"{lo.lora_name}.{what}: rel err {r:.3e}"
+    glob = (tot_num / tot_den) ** 0.5
+    assert glob < tol / 3, f"global LoRA-grad rel err {glob:.3e}"
+    print(f"{model} {dtype} {method}: worst per-module grad err {worst:.2e}, global {glob:.2e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_interleaved_frozen_pass_does_not_clobber_tape(dtype):
+    """forward(grad) -> forward(no grad) -> backward: the frozen pass must not disturb saved activations."""
+    ocfg, ou, onet, pu, pnet = build_pair("tiny_sd1x", dtype)
+    x, ctx, add = inputs(ocfg, 2, 16)
+    gy = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(9)).cuda() * 1e-3
+    with pnet:
+        a = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda()).sample
+    (a * gy).sum().backward()
+    g1 = pnet.flat_up.grad.clone()
+    pnet.flat_up.grad = None
+    pnet.flat_down.grad = None
+    with pnet:
+        b = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda()).sample
+    with torch.no_grad():
+        pnet.__exit__(None, None, None)
+        pu(x.cuda() * 0.5, 20.0, encoder_hidden_states=ctx.cuda() * 2).sample
+    (b * gy).sum().backward()
+    torch.testing.assert_close(pnet.flat_up.grad, g1, rtol=0, atol=0)  # deterministic kernels: bitwise equal
+
+
+def test_smaller_batch_than_engine_capacity():
+    ocfg, ou, onet, pu, pnet = build_pair("tiny_sdxl", torch.float16)
+    x, ctx, add = inputs(ocfg, 4, 16)
+    pnet.__exit__(None, None, None)
+    with torch.no_grad():
+        full = pu(x.cuda(), 300.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+        sub = pu(x[:2].cuda(), 300.0, encoder_hidden_states=ctx[:2].cuda(),
+                 added_cond_kwargs={k: v[:2].cuda() for k, v in add.items()}).sample
+    torch.testing.assert_close(sub, full[:2], rtol=0, atol=0)

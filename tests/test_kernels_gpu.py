@@ -1,0 +1,281 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel, called through the C ABI (include/smi.h `smi_op_*`),
+against a plain PyTorch fp32 reference of the same op computed from the SAME 16-bit-rounded inputs.
+
+Tolerance convention (written per test): outputs are stored in fp16/bf16, so the comparison allows one storage
+rounding of the result (2^-11 rel. for fp16, 2^-8 for bf16) on top of fp32 accumulation-order noise."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float16, torch.bfloat16]
+EPS = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sliders_conceptmod_amd import _native
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return _native.lib()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def chk(lib, rc):
+    assert rc == 0, lib.smi_last_error().decode()
+
+
+def dcode(dt):
+    return 0 if dt == torch.float16 else 1
+
+
+def rnd(*shape, dt, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(dt)
+
+
+def close(a, b, dt, mult=4.0, what=""):
+    a, b = a.float(), b.float()
+    tol = EPS[dt] * mult
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+    assert err <= tol * (ref + 1e-6) and rel <= tol, f"{what}: max err {err:.3e} (ref max {ref:.3e}), rel-norm {rel:.3e}, tol {tol:.2e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 320), (4096, 640, 640), (77 * 2, 1280, 2048),
+                                   (2, 1280, 320), (1000, 4, 2880), (300, 1284, 72)])
+def test_gemm_plain_and_tails(lib, dt, M, N, K):
+    a, w = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    c = torch.empty(M, N, device="cuda", dtype=dt)
+    chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c), M, N, K, None, None, None, None, 0, 0.0, 0, None))
+    close(c, a.float() @ w.float().t(), dt, what="gemm")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_asymmetric_identity_catches_transposed_writes(lib, dt):
+    """A = I with an asymmetric W: a row/col swap in the C fragment map cannot hide (cdna guide section 3)."""
+    M = N = K = 128
+    a = torch.eye(M, device="cuda").to(dt)
+    w = (torch.arange(N, device="cuda")[:, None] * 3 + torch.arange(K, device="cuda")[None, :] * 0.25).to(dt)
+    c = torch.empty(M, N, device="cuda", dtype=dt)
+    chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c), M, N, K, None, None, None, None, 0, 0.0, 0, None))
+    assert torch.equal(c.float(), w.float().t())
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("r", [4, 8, 3])
+def test_gemm_full_epilogue(lib, dt, r):
+    M, N, K = 520, 640, 320
+    a, w = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    bias, res = rnd(N, dt=dt, seed=3), rnd(M, N, dt=dt, seed=4)
+    xa = torch.randn(M, r, device="cuda")
+    up = torch.randn(N, r, device="cuda") * 0.1
+    s = 0.375
+    c = torch.empty(M, N, device="cuda", dtype=dt)
+    chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up), r, s, 0, None))
+    ref = a.float() @ w.float().t() + bias.float() + res.float() + s * (xa @ up.t())
+    close(c, ref, dt, what="gemm+bias+res+lora")
+    c32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c32), M, N, K, P(bias), None, None, None, 0, 0.0, 1, None))
+    torch.testing.assert_close(c32, a.float() @ w.float().t() + bias.float(), rtol=2e-5, atol=2e-4)
+
+
+def pack_fwd(w):  # [Cout, Cin, 3, 3] -> [Cout, 9*Cin] in (ky, kx, ci) order
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def pack_grad(w, flip):  # -> [Cin, 9*Cout], taps flipped for stride-1 gradients
+    wt = w.flip(2, 3) if flip else w
+    return wt.permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("nb,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320)])
+def test_conv3x3_forward_and_input_gradient(lib, dt, nb, H, W, Cin, Cout):
+    x = rnd(nb, H, W, Cin, dt=dt, seed=1)  # NHWC
+    w = rnd(Cout, Cin, 3, 3, dt=dt, scale=(9 * Cin) ** -0.5, seed=2)
+    b = rnd(Cout, dt=dt, seed=3)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    for stride, ups in [(1, 0), (2, 0), (1, 1)]:
+        Ho = (H + 1) // 2 if stride == 2 else (2 * H if ups else H)
+        Wo = (W + 1) // 2 if stride == 2 else (2 * W if ups else W)
+        y = torch.empty(nb, Ho, Wo, Cout, device="cuda", dtype=dt)
+        chk(lib, lib.smi_op_conv3x3(dcode(dt), P(x), P(pack_fwd(w)), P(b), P(y), nb, H, W, Cin, Cout, stride, ups, 0,
+                                    Ho, Wo, None))
+        xin = F.interpolate(xr, scale_factor=2.0, mode="nearest") if ups else xr
+        ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1)
+        close(y.permute(0, 3, 1, 2), ref, dt, what=f"conv s{stride} u{ups}")
+        # input gradient through the same kernel: flipped/transposed filters; stride 2 uses the transposed gather
+        gy = rnd(nb, Ho, Wo, Cout, dt=dt, seed=5)
+        (gref,) = torch.autograd.grad(ref, xr, gy.float().permute(0, 3, 1, 2))
+        if ups:
+            gu = torch.empty(nb, Ho, Wo, Cin, device="cuda", dtype=dt)
+            chk(lib, lib.smi_op_conv3x3(dcode(dt), P(gy), P(pack_grad(w, True)), None, P(gu), nb, Ho, Wo, Cout, Cin, 1,
+                                        0, 0, Ho, Wo, None))
+            gx = gu.float().view(nb, H, 2, W, 2, Cin).sum(dim=(2, 4))
+            close(gx.permute(0, 3, 1, 2), gref, dt, mult=8, what="conv-upsample dX")
+        else:
+            gx = torch.empty(nb, H, W, Cin, device="cuda", dtype=dt)
+            chk(lib, lib.smi_op_conv3x3(dcode(dt), P(gy), P(pack_grad(w, stride == 1)), None, P(gx), nb, Ho, Wo, Cout,
+                                        Cin, stride, 0, 1 if stride == 2 else 0, H, W, None))
+            close(gx.permute(0, 3, 1, 2), gref, dt, what=f"conv s{stride} dX")
+
+
+def attn_ref(q, k, v, scale):
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v), torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 4, 256, 256, 64), (1, 2, 64, 77, 40), (2, 3, 320, 77, 64),
+                                          (1, 2, 128, 128, 160), (2, 8, 1024, 1024, 64), (1, 2, 96, 200, 80),
+                                          (1, 2, 64, 64, 32), (1, 1, 48, 33, 16)])
+def test_attention_forward_backward(lib, dt, B, H, Nq, Nk, D):
+    q, k, v = rnd(B, Nq, H, D, dt=dt, seed=1), rnd(B, Nk, H, D, dt=dt, seed=2), rnd(B, Nk, H, D, dt=dt, seed=3)
+    scale = D ** -0.5
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, Nq, device="cuda")
+    chk(lib, lib.smi_op_attention_fwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), B, H, Nq, Nk, D, scale, None))
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    oref, lref = attn_ref(qf, kf, vf, scale)
+    close(o, oref, dt, what="attn O")
+    torch.testing.assert_close(lse, lref, rtol=1e-4, atol=2e-3)
+    do = rnd(B, Nq, H, D, dt=dt, seed=4)
+    gq, gk, gv = torch.autograd.grad(oref, (qf, kf, vf), do.float())
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Nq, device="cuda")
+    chk(lib, lib.smi_op_attention_bwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), P(do), P(dq), P(dk), P(dv), P(delta),
+                                      B, H, Nq, Nk, D, scale, None))
+    # P and dS are rounded to 16 bit before their MFMAs: allow a few storage roundings
+    close(dq, gq, dt, mult=8, what="attn dQ")
+    close(dk, gk, dt, mult=8, what="attn dK")
+    close(dv, gv, dt, mult=8, what="attn dV")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_attention_rescale_branch_with_spiked_key(lib, dt):
+    """Forces the online-softmax running max to jump in a LATE key tile (guide rule 26)."""
+    B, H, N, D = 1, 1, 256, 64
+    q, k, v = rnd(B, N, H, D, dt=dt, seed=1), rnd(B, N, H, D, dt=dt, seed=2), rnd(B, N, H, D, dt=dt, seed=3)
+    k[0, 200, 0] = (q[0, 5, 0].float() * 6).to(dt)  # key 200 (4th tile) dominates query 5
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, device="cuda")
+    chk(lib, lib.smi_op_attention_fwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), B, H, N, N, D, D ** -0.5, None))
+    oref, _ = attn_ref(q.float(), k.float(), v.float(), D ** -0.5)
+    close(o, oref, dt, what="attn O (spiked)")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("nb,HW,Cc,G,silu", [(2, 256, 320, 32, 1), (3, 64, 64, 16, 0), (2, 1000, 2560, 32, 1),
+                                             (1, 4096, 640, 32, 1), (2, 100, 1920, 32, 0)])
+def test_groupnorm_forward_backward(lib, dt, nb, HW, Cc, G, silu):
+    x = rnd(nb, HW, Cc, dt=dt, seed=1) * 2 + 0.5
+    gamma, beta = (1 + 0.1 * rnd(Cc, dt=dt, seed=2)).to(dt), rnd(Cc, dt=dt, scale=0.1, seed=3)
+    dy = rnd(nb, HW, Cc, dt=dt, seed=4)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    nchunk = (HW + 255) // 256
+    scratch = torch.empty(2 * nb * Cc + nb * G * 2 + nb * nchunk * G * 2 + 2 * nb * Cc + 64, device="cuda")
+    chk(lib, lib.smi_op_groupnorm(dcode(dt), P(x), P(gamma), P(beta), P(y), P(dy), P(dx), P(scratch), nb, HW, Cc, G,
+                                  1e-5, silu, None))
+    xr = x.float().permute(0, 2, 1).requires_grad_(True)  # [n, C, HW]
+    ref = F.group_norm(xr, G, gamma.float(), beta.float(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    close(y.permute(0, 2, 1), ref, dt, what="groupnorm y")
+    (gref,) = torch.autograd.grad(ref, xr, dy.float().permute(0, 2, 1))
+    close(dx.permute(0, 2, 1), gref, dt, mult=6, what="groupnorm dx")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,Cc", [(1000, 320), (4096, 1280), (77, 640), (5, 64)])
+def test_layernorm_forward_backward(lib, dt, M, Cc):
+    x = rnd(M, Cc, dt=dt, seed=1) * 1.5 - 0.3
+    gamma, beta = (1 + 0.1 * rnd(Cc, dt=dt, seed=2)).to(dt), rnd(Cc, dt=dt, scale=0.1, seed=3)
+    dy = rnd(M, Cc, dt=dt, seed=4)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    st = torch.empty(M, 2, device="cuda")
+    chk(lib, lib.smi_op_layernorm(dcode(dt), P(x), P(gamma), P(beta), P(y), P(dy), P(dx), P(st), M, Cc, 1e-5, None))
+    xr = x.float().requires_grad_(True)
+    ref = F.layer_norm(xr, (Cc,), gamma.float(), beta.float(), 1e-5)
+    close(y, ref, dt, what="layernorm y")
+    (gref,) = torch.autograd.grad(ref, xr, dy.float())
+    close(dx, gref, dt, mult=6, what="layernorm dx")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_geglu_forward_backward(lib, dt):
+    M, C4 = 777, 1280
+    pj, do = rnd(M, 2 * C4, dt=dt, seed=1), rnd(M, C4, dt=dt, seed=2)
+    out, dpj = torch.empty(M, C4, device="cuda", dtype=dt), torch.empty_like(pj)
+    chk(lib, lib.smi_op_geglu(dcode(dt), P(pj), P(out), P(do), P(dpj), M, C4, None))
+    pr = pj.float().requires_grad_(True)
+    h, g = pr.chunk(2, dim=-1)
+    ref = h * F.gelu(g)
+    close(out, ref, dt, what="geglu")
+    (gref,) = torch.autograd.grad(ref, pr, do.float())
+    close(dpj, gref, dt, what="geglu grad")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,K,r", [(4096, 640, 4), (1000, 1280, 8), (154, 2048, 4), (70, 320, 3), (600, 64, 16)])
+def test_lora_skinny_kernels(lib, dt, M, K, r):
+    x = rnd(M, K, dt=dt, seed=1)
+    a = torch.randn(r, K, device="cuda") * 0.05
+    xa = torch.empty(M, r, device="cuda")
+    chk(lib, lib.smi_op_lora_down(dcode(dt), P(x), P(a), P(xa), M, K, r, None))
+    torch.testing.assert_close(xa, x.float() @ a.t(), rtol=1e-4, atol=1e-4)
+    p = torch.randn(M, r, device="cuda")
+    dw = torch.ones(r, K, device="cuda")  # the kernel accumulates (+=)
+    scratch = torch.empty(((M + 511) // 512) * r * K + 16, device="cuda")
+    chk(lib, lib.smi_op_lora_wgrad(dcode(dt), P(p), P(x), P(dw), M, K, r, 0.5, P(scratch), None))
+    torch.testing.assert_close(dw, 1 + 0.5 * (p.t() @ x.float()), rtol=1e-4, atol=2e-3)
+
+
+def test_step_ops_match_torch(lib):
+    from oracle import slider_ref as R
+    g = torch.Generator(device="cuda").manual_seed(0)
+    n = 2 * 4 * 32 * 32
+    e2 = torch.randn(2 * n, device="cuda", generator=g)
+    out = torch.empty(n, device="cuda")
+    chk(lib, lib.smi_cfg_combine(P(e2), P(out), n, 3.0, None))
+    torch.testing.assert_close(out, e2[:n] + 3.0 * (e2[n:] - e2[:n]), rtol=1e-6, atol=1e-6)
+    t, po, ne, ng = (torch.randn(n, device="cuda", generator=g) for _ in range(4))
+    loss, dt_ = torch.empty(1, device="cuda"), torch.empty(n, device="cuda")
+    scratch = torch.empty(2048, device="cuda")
+    for action, sign in (("enhance", 4.0), ("erase", -4.0)):
+        chk(lib, lib.smi_slider_loss(P(t), P(po), P(ne), P(ng), sign, n, P(loss), P(dt_), P(scratch), None))
+        tr = t.clone().requires_grad_(True)
+        ref = R.slider_loss(action, 4.0, tr, po, ne, ng)
+        ref.backward()
+        torch.testing.assert_close(loss[0], ref.detach(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(dt_, tr.grad, rtol=1e-5, atol=1e-9)
+    # clip + AdamW, 3 steps, against the oracle's restatement of torch's update
+    p = torch.randn(5000, device="cuda", generator=g)
+    pr = p.clone().cpu()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    mr, vr = torch.zeros(5000), torch.zeros(5000)
+    for step in range(1, 4):
+        gr = torch.randn(5000, device="cuda", generator=g) * 0.3
+        chk(lib, lib.smi_clip_adamw(P(p), P(gr), P(m), P(v), 5000, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step, 0.2, P(scratch),
+                                    None))
+        holder = torch.nn.Parameter(pr.clone())
+        holder.grad = gr.cpu().clone()
+        R.clip_grad_norm_([holder], 0.2)
+        with torch.no_grad():
+            R.adamw_step_(pr, holder.grad, mr, vr, step, 1e-2, weight_decay=1e-2)
+        torch.testing.assert_close(p.cpu(), pr, rtol=2e-5, atol=2e-6)
+    x = torch.randn(n, device="cuda", generator=g)
+    e, nz = torch.randn(n, device="cuda", generator=g), torch.randn(n, device="cuda", generator=g)
+    xr = x.clone()
+    chk(lib, lib.smi_sched_step(P(x), P(e), P(nz), 0.9, -0.2, 0.05, n, None))
+    torch.testing.assert_close(x, 0.9 * xr - 0.2 * e + 0.05 * nz, rtol=1e-6, atol=1e-6)
