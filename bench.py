@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""bench.py -- slider train-steps/sec (BASELINE.json metric) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config sdxl_1024_b2_r4|sd15_512_b4_r4|...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: 3 frozen UNet
+forwards + 1 LoRA-adapted forward + backward + guidance loss + global-norm clip + AdamW (+ all-reduce of the flat
+LoRA gradient when N > 1), all on the CFG-doubled UNet batch 2B exactly as the reference computes it
+(train_lora_xl.py:240-351).  The stochastic pre-roll (`diffusion_xl`) is excluded: synthetic `denoised_latents` are
+supplied directly, resident in HBM before the timed region.  Weights are random-init of the real architecture
+(no checkpoints offline) -- "data": "synthetic".
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel class (the MFMA gemm_nt_kernel: Linear + implicit-GEMM conv launches), algorithmic
+                  FLOPs / device time measured with HIP events on the launch stream in a separate profiled step
+  cpu_baseline -- the CPU oracle (oracle/unet_ref.py, kind "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (model, resolution, per-GPU batch B, rank, dtype, scheduler, max_grad_norm, lr, wd)
+    "sdxl_1024_b2_r4": ("sdxl", 1024, 2, 4, "fp16", "euler_a", 0.2, 1e-4, 1e-6),   # BASELINE configs[2] (headline)
+    "sdxl_1024_b2_r8": ("sdxl", 1024, 2, 8, "fp16", "euler_a", 0.2, 1e-4, 1e-6),   # configs[3] per-GPU shard
+    "sd15_512_b4_r4": ("sd1x", 512, 4, 4, "bf16", "ddim", 0.0, 2e-4, 1e-2),        # configs[1]
+    "sd14_512_b1_r4": ("sd1x", 512, 1, 4, "fp16", "ddim", 0.0, 2e-4, 1e-2),        # configs[0] shape on the GPU
+    "tiny_sdxl": ("tiny_sdxl", 128, 2, 4, "fp16", "euler_a", 0.2, 1e-4, 1e-6),
+}
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+
+
+def unet_cfg(model):
+    import sliders_conceptmod_amd.unet as PU
+    if model == "sdxl":
+        return PU.sdxl_config()
+    if model == "sd1x":
+        return PU.sd1x_config()
+    if model == "tiny_sdxl":
+        return PU.UNetConfig(block_out_channels=(64, 128, 256),
+                             down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                             up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                             transformer_layers_per_block=(1, 2, 3), num_attention_heads=(2, 4, 8),
+                             cross_attention_dim=64, norm_num_groups=16, use_linear_projection=True,
+                             addition_embed_type="text_time", addition_time_embed_dim=32,
+                             projection_class_embeddings_input_dim=256)
+    raise ValueError(model)
+
+
+@torch.no_grad()
+def init_synthetic_on_device(module, seed):
+    """Seeded fan-in-scaled weights generated directly in HBM (SURVEY.md section 8d 'Synthetic inputs')."""
+    import math
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for name, p in module.named_parameters():
+        if p.ndim >= 2:
+            w = torch.randn(p.shape, generator=g, device="cuda") * (0.7 / math.sqrt(p[0].numel()))
+        elif name.endswith("weight"):
+            w = 1.0 + 0.1 * torch.randn(p.shape, generator=g, device="cuda")
+        else:
+            w = 0.02 * torch.randn(p.shape, generator=g, device="cuda")
+        p.copy_(w.to(p.dtype))
+
+
+def algorithmic_step_flops(engine_profile):
+    return sum(v["flops"] for v in engine_profile.values())
+
+
+def cpu_baseline(model, rank_, step_flops, seconds_budget=25.0):
+    """Times the CPU oracle (a port: oracle/unet_ref.py) on this box's host cores on a bounded sample of the same
+    workload: UNet forwards at reduced latent size, converted to steps/s by the algorithmic FLOP ratio."""
+    from oracle import unet_ref as OU
+    # the GPU box grants a 16-core share per GPU whatever os.cpu_count() says; oversubscribing it is far slower
+    ncores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    ocfg = {"sdxl": OU.sdxl_config, "sd1x": OU.sd1x_config, "tiny_sdxl": OU.tiny_sdxl_config}[model]()
+    with torch.no_grad():
+        ou = OU.UNet2DConditionModel(ocfg)
+        for p in ou.parameters():  # cheap deterministic fill: timing does not depend on the values
+            p.uniform_(-0.02, 0.02)
+        ou.eval()
+        lat = 32 if model != "tiny_sdxl" else 16
+        n = 2
+        x = torch.randn(n, 4, lat, lat)
+        ctx = torch.randn(n, 77, ocfg.cross_attention_dim)
+        add = None
+        if ocfg.addition_embed_type == "text_time":
+            pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
+            add = {"text_embeds": torch.randn(n, pdim), "time_ids": torch.tensor([[256.0, 256, 0, 0, 256, 256]] * n)}
+        # FLOPs of the sample, counted by hooks on Linear / Conv2d (+ attention analytically)
+        flops = [0.0]
+
+        def lin_hook(m, inp, out):
+            flops[0] += 2.0 * out.numel() * m.in_features
+
+        def conv_hook(m, inp, out):
+            flops[0] += 2.0 * out.numel() * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+
+        def attn_hook(m, args, kwargs, out):
+            xq = args[0]
+            ctx_ = kwargs.get("context", args[1] if len(args) > 1 else None)
+            nk = xq.shape[1] if ctx_ is None else ctx_.shape[1]
+            flops[0] += 4.0 * xq.shape[0] * xq.shape[1] * nk * m.to_q.out_features
+
+        hs = []
+        for m in ou.modules():
+            if isinstance(m, torch.nn.Linear):
+                hs.append(m.register_forward_hook(lin_hook))
+            elif isinstance(m, torch.nn.Conv2d):
+                hs.append(m.register_forward_hook(conv_hook))
+            elif m.__class__.__name__ == "Attention":
+                hs.append(m.register_forward_hook(attn_hook, with_kwargs=True))
+        ou(x, 499.0, ctx, add)  # warm-up + FLOP count
+        for h in hs:
+            h.remove()
+        sample_flops = flops[0]
+        t0 = time.time()
+        reps = 0
+        while True:
+            ou(x, 499.0, ctx, add)
+            reps += 1
+            if time.time() - t0 > seconds_budget or reps >= 8:
+                break
+        dt = (time.time() - t0) / reps
+    cpu_flops_per_s = sample_flops / dt
+    return {
+        "value": cpu_flops_per_s / step_flops, "unit": "steps/s", "cores": ncores, "kind": "port",
+        "sample": f"oracle/unet_ref.py {model} UNet forward, fp32, batch {n} at {lat}x{lat} latents, {reps} reps, "
+                  f"{dt:.2f} s each = {cpu_flops_per_s / 1e12:.3f} TFLOP/s on {ncores} threads; steps/s extrapolated by "
+                  f"algorithmic FLOPs ({sample_flops / 1e12:.3f} TFLOP per sample vs {step_flops / 1e12:.1f} per step)",
+    }
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="sdxl_1024_b2_r4")
+    ap.add_argument("--skip-dead-cfg-half", action="store_true",
+                    help="drop the algebraically dead unconditional half (CFG scale 1); reported separately")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from sliders_conceptmod_amd import build as smi_build
+    if rank == 0:
+        smi_build.build()
+    if world > 1:
+        torch.distributed.barrier()
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.model_util as MU
+    import sliders_conceptmod_amd.unet as PU
+    from sliders_conceptmod_amd.step import SliderStep
+
+    model, res, B, lrank, dt_name, sched_name, max_norm, lr, wd = CONFIGS[args.config]
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[dt_name]
+    cfg = unet_cfg(model)
+    xl = cfg.addition_embed_type == "text_time"
+    with torch.device("cuda"):
+        unet = PU.UNet2DConditionModel(cfg).to(dtype)
+    init_synthetic_on_device(unet, seed=0)
+    unet.requires_grad_(False).eval()
+    if rank == 0:
+        log(f"{args.config}: weights initialised ({sum(p.numel() for p in unet.parameters()) / 1e6:.0f} M params)")
+    torch.manual_seed(1)
+    net = L.LoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn").to("cuda")
+    with torch.no_grad():  # non-zero up weights so no kernel can short-circuit
+        net.flat_up.copy_(torch.randn(net.flat_up.shape, generator=torch.Generator().manual_seed(2)) * 1e-2)
+    sched = MU.create_noise_scheduler(sched_name)
+    sched.set_timesteps(1000)
+    timestep = sched.timesteps[500]  # t = 499
+
+    g = torch.Generator().manual_seed(4 + rank)
+    keys = ["target", "positive", "neutral", "unconditional"] + (["negative"] if xl else [])
+    emb = {k: torch.randn(1, 77, cfg.cross_attention_dim, generator=g) for k in keys}
+    pooled = time_ids = None
+    if xl:
+        pdim = cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim
+        pooled = {k: torch.randn(1, pdim, generator=g) for k in keys}
+        time_ids = torch.tensor([[float(res), float(res), 0.0, 0.0, float(res), float(res)]])
+    step = SliderStep(unet, net, sched, lr=lr, weight_decay=wd, max_grad_norm=max_norm, cfg_scale=1.0,
+                      skip_dead_cfg_half=args.skip_dead_cfg_half)
+    cond = step.make_conditioning(emb, B, pooled, time_ids)
+    lat = res // 8
+    denoised = torch.randn(B, 4, lat, lat, generator=torch.Generator().manual_seed(3 + rank)).cuda()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step.train_step(denoised, timestep, cond, "enhance", 4.0)
+        if i == 0:
+            torch.cuda.synchronize()
+            if rank == 0:
+                log("first step done (engine created, weights packed)")
+    sync()
+    if rank == 0:
+        log("warm-up done; timing")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step.train_step(denoised, timestep, cond, "enhance", 4.0)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(te.item())
+    loss_val = float(loss.item())
+    if rank == 0:
+        log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step; profiling one step")
+
+    # ---- separate profiled step: per-kernel-class device time from HIP events on the launch stream
+    engine = unet._engine
+    engine.profile_enable(True)
+    step.train_step(denoised, timestep, cond, "enhance", 4.0)
+    prof = engine.profile_read()
+    engine.profile_enable(False)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        step_flops = algorithmic_step_flops(prof)
+        mm_ms = prof["gemm"]["ms"] + prof["conv"]["ms"]
+        mm_fl = prof["gemm"]["flops"] + prof["conv"]["flops"]
+        mm_la = prof["gemm"]["launches"] + prof["conv"]["launches"]
+        achieved = mm_fl / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0
+        out = {
+            "metric": "slider train-steps/sec (4-pass UNet fwd+bwd)",
+            "value": world * args.steps / elapsed,
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dt_name, "data": "synthetic",
+            "config": {"workload": args.config, "unet": model, "resolution": res, "per_gpu_batch": B,
+                       "unet_batch": B if args.skip_dead_cfg_half else 2 * B, "global_batch": B * world,
+                       "lora_rank": lrank, "train_method": "noxattn", "lora_params": int(net.flat.numel()),
+                       "scheduler": sched_name, "parallelism": f"dp{world}", "pre_roll": "excluded",
+                       "skip_dead_cfg_half": bool(args.skip_dead_cfg_half)},
+            "samples_per_s": args.steps * B * world / elapsed,
+            "loss": loss_val,
+            "step_algorithmic_tflop": step_flops / 1e12,
+            "step_tflops_achieved": step_flops / 1e12 / (ms_per_step * 1e-3),
+            "step_frac_of_mfma_peak": step_flops / 1e12 / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS,
+            "roofline": {"kernel": "gemm_nt_kernel (Linear GEMMs + implicit-GEMM 3x3 convs)", "bound": "mfma",
+                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": int(mm_la), "avg_launch_us": mm_ms * 1e3 / max(mm_la, 1),
+                         "algorithmic_tflop_per_step": mm_fl / 1e12,
+                         "share_of_step_device_time": mm_ms / max(sum(v["ms"] for v in prof.values()), 1e-9)},
+            "kernel_classes": {k: {"ms": round(v["ms"], 3), "launches": int(v["launches"]),
+                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] else None,
+                                   "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] else None}
+                               for k, v in prof.items()},
+        }
+        # weak scaling: a unit is one 4-pass step on one per-GPU batch B; all ranks together process world*steps units
+        if world == 1 and not args.no_cpu_baseline:
+            log("GPU part done; timing the CPU oracle sample: " + json.dumps({k: out[k] for k in ("value", "ms_per_step")}))
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, rank, step_flops)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,21 @@ int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, 
  * Replaces loss.backward() through the UNet (train_lora.py:298). */
 int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat, float* d_lora_up_flat);
 
+/* Per-kernel-class timing, measured with HIP events recorded on the engine's stream around every launch
+ * (measurement aid for bench.py's roofline; off by default, adds two event records per launch when on).
+ * smi_profile_read synchronises with the host and returns, per class, the summed device time (ms), the algorithmic
+ * FLOPs (2*M*N*K per GEMM/conv; 4*B*H*Nq*Nk*D per attention forward, 10*... per attention backward), the
+ * algorithmic HBM bytes (operands read once + result written once) and the launch count since the last enable. */
+#define SMI_PROF_GEMM 0  /* gemm_nt_kernel, dense operand (all Linear layers, 1x1 convs)  */
+#define SMI_PROF_CONV 1  /* gemm_nt_kernel, implicit-GEMM 3x3 conv (+ the small-channel direct conv) */
+#define SMI_PROF_ATTN 2  /* attention forward / backward kernels */
+#define SMI_PROF_NORM 3  /* GroupNorm / LayerNorm */
+#define SMI_PROF_ELEM 4  /* GEGLU, SiLU, add, concat/split copies, pooling */
+#define SMI_PROF_LORA 5  /* LoRA down-projection and weight-gradient reductions */
+#define SMI_PROF_NCAT 6
+int smi_profile_enable(smi_engine* e, int enable);
+int smi_profile_read(smi_engine* e, double* ms, double* flops, double* bytes, int64_t* launches);
+
 /* out[i] = u[i] + g * (t[i] - u[i]) over the two halves of a CFG-doubled prediction   (train_util.py:297-300) */
 int smi_cfg_combine(const float* eps_2n, float* out_n, int64_t n_half, float guidance_scale, void* stream);
 

@@ -53,6 +53,9 @@ _SIGS = {
     "smi_unet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "smi_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "smi_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int64)]),
     "smi_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "smi_slider_loss": (C.c_int, [C.c_void_p] * 4 + [C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p]),
@@ -201,6 +204,19 @@ class Engine:
 
     def backward(self, d_eps: torch.Tensor, d_down: torch.Tensor, d_up: torch.Tensor):
         check(lib().smi_unet_backward(self.handle, ptr(d_eps), ptr(d_down), ptr(d_up)), "smi_unet_backward")
+
+    PROF_CLASSES = ("gemm", "conv", "attention", "norm", "elementwise", "lora")
+
+    def profile_enable(self, on: bool):
+        check(lib().smi_profile_enable(self.handle, int(on)), "smi_profile_enable")
+
+    def profile_read(self) -> dict:
+        n = len(self.PROF_CLASSES)
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        la = (C.c_int64 * n)()
+        check(lib().smi_profile_read(self.handle, ms, fl, by, la), "smi_profile_read")
+        return {k: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": la[i]}
+                for i, k in enumerate(self.PROF_CLASSES)}
 
     def close(self):
         if getattr(self, "handle", None):

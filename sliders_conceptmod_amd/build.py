@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsmi_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "lora.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "norm.hip", "elementwise.hip", "lora.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

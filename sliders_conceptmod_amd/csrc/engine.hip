@@ -46,15 +46,22 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------
 // weight packing kernels (run once at creation)
 // ------------------------------------------------------------------------------------------------------------
+// dst[c][col0 + r] = src[r][c] through a 64x64 LDS tile: coalesced reads and writes
 template <typename T>
-__global__ void pack_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int C, int ldd,
-                                      int col0) {
-  // dst[c][col0 + r] = src[r][c]
-  const int64_t total = (int64_t)R * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int64_t r = i / C;
-    dst[(int64_t)c * ldd + col0 + r] = src[i];
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R,
+                                                             int C, int ldd, int col0) {
+  __shared__ T tile[64][66];
+  const int tilesC = (C + 63) / 64;
+  const int tr = (blockIdx.x / tilesC) * 64, tc = (blockIdx.x % tilesC) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = tr + i, c = tc + tx;
+    if (r < R && c < C) tile[i][tx] = src[(int64_t)r * C + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = tc + i, r = tr + tx;
+    if (r < R && c < C) dst[(int64_t)c * ldd + col0 + r] = tile[tx][i];
   }
 }
 // conv weight [Cout, Cin, 3, 3] -> forward pack  dst[co][(ky*3+kx)*Cin + ci]
@@ -222,6 +229,67 @@ struct smi_engine {
       }                                    \
     }                                      \
   } while (0)
+  // same, attributing the launch (and its algorithmic FLOPs / HBM bytes) to a kernel class for smi_profile_*
+#define RUNP(cat, flops, bytes, call)      \
+  do {                                     \
+    if (!dry && !err) {                    \
+      prof_begin(cat, flops, bytes);       \
+      if ((call) != 0) {                   \
+        err = true;                        \
+      }                                    \
+      prof_end();                          \
+    }                                      \
+  } while (0)
+
+  // ---- per-kernel-class timing with HIP events on the engine's stream (profiling mode only)
+  bool prof_on = false;
+  struct ProfEv {
+    int cat;
+    hipEvent_t a, b;
+  };
+  std::vector<ProfEv> prof_ev;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[SMI_PROF_NCAT] = {0};
+  double prof_flops[SMI_PROF_NCAT] = {0};
+  double prof_bytes[SMI_PROF_NCAT] = {0};
+  int64_t prof_launches[SMI_PROF_NCAT] = {0};
+  hipEvent_t prof_event() {
+    if (!prof_pool.empty()) {
+      hipEvent_t e = prof_pool.back();
+      prof_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void prof_begin(int cat, double flops, double bytes) {
+    if (!prof_on) return;
+    ProfEv pe;
+    pe.cat = cat;
+    pe.a = prof_event();
+    pe.b = prof_event();
+    (void)hipEventRecord(pe.a, stream);
+    prof_ev.push_back(pe);
+    prof_flops[cat] += flops;
+    prof_bytes[cat] += bytes;
+    prof_launches[cat] += 1;
+  }
+  void prof_end() {
+    if (!prof_on) return;
+    (void)hipEventRecord(prof_ev.back().b, stream);
+  }
+  void prof_collect() {  // host-synchronising
+    for (auto& pe : prof_ev) {
+      (void)hipEventSynchronize(pe.b);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, pe.a, pe.b);
+      prof_ms[pe.cat] += ms;
+      prof_pool.push_back(pe.a);
+      prof_pool.push_back(pe.b);
+    }
+    prof_ev.clear();
+  }
 
   Ten* new_ten(int64_t rows, int cols, int n = 0, int H = 0, int W = 0, size_t elt = 0) {
     tens->emplace_back();
@@ -255,7 +323,7 @@ struct smi_engine {
     if (!t->g) {
       t->g = g;  // alias: g is dead after its producer's closure
     } else {
-      RUN(launch_add(dtype, t->g, g, t->g, t->rows * t->cols, stream));
+      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, t->g, g, t->g, t->rows * t->cols, stream));
     }
   }
 
@@ -293,8 +361,7 @@ struct smi_engine {
 
   void transpose_into(const void* src, void* dst, int R, int C, int ldd, int col0) {
     if (dry || err || !src) return;
-    const int64_t total = (int64_t)R * C;
-    const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    const int grid = ((R + 63) / 64) * ((C + 63) / 64);
     if (dtype == DT_F16)
       hipLaunchKernelGGL(pack_transpose_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, R, C, ldd, col0);
     else
@@ -536,7 +603,7 @@ struct smi_engine {
     const float lscale = mult * L.scale;
     if (lon) {
       xa = alloc_f32((size_t)x->rows * rtot);
-      RUN(launch_lora_down(dtype, x->p, x->cols, lora_down + L.off_down, L.in, 1, xa, rtot, (int)x->rows, L.in, rtot,
+      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_down(dtype, x->p, x->cols, lora_down + L.off_down, L.in, 1, xa, rtot, (int)x->rows, L.in, rtot,
                            stream));
     }
     GemmParams p;
@@ -564,7 +631,8 @@ struct smi_engine {
       p.lora_seg = L.nseg > 1 ? L.out / L.nseg : 0;
       p.lora_scale = lscale;
     }
-    RUN(launch_gemm(p, stream));
+    RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
+         launch_gemm(p, stream));
     y->ng = lon || x->ng || (res && res->ng);
     if (saving && y->ng) {
       const Lin* Lp = &L;
@@ -587,15 +655,15 @@ struct smi_engine {
       for (int s = 0; s < L->nseg; ++s) {
         const char* dys = (const char*)dy + (size_t)s * cs * esz();
         // d(up_s)[n][q] += lscale/S * sum_m dy[m][s*cs+n] * xa[m][s*r+q]
-        RUN(launch_lora_wgrad(dtype, xa + s * r, rtot, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
+        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, xa + s * r, rtot, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
                               cs, r, lscale, gscale + 1, scratch, stream));
         // dxa_s[m][q] = sum_n dy[m][s*cs+n] * up_s[n][q]
-        RUN(launch_lora_down(dtype, dys, L->out, bw_up + L->off_up + (int64_t)s * cs * r, 1, r, dxa + s * r, rtot,
+        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_down(dtype, dys, L->out, bw_up + L->off_up + (int64_t)s * cs * r, 1, r, dxa + s * r, rtot,
                              M, cs, r, stream));
       }
       for (int s = 0; s < L->nseg; ++s) {
         // d(down_s)[q][k] += lscale/S * sum_m dxa[m][s*r+q] * x[m][k]
-        RUN(launch_lora_wgrad(dtype, dxa + s * r, rtot, x->p, x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
+        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, rtot, x->p, x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
                               L->in, 1, M, L->in, r, lscale, gscale + 1, scratch, stream));
       }
     }
@@ -631,14 +699,15 @@ struct smi_engine {
         p.lora_seg = 0;
         p.lora_scale = lscale;
       }
-      RUN(launch_gemm(p, stream));
+      RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
+           launch_gemm(p, stream));
     }
   }
 
   Ten* layernorm(Ten* x, const Norm& nm) {
     Ten* y = new_ten(x->rows, x->cols, x->n, x->H, x->W);
     float* st = alloc_f32((size_t)x->rows * 2);
-    RUN(launch_layernorm_fwd(dtype, x->p, nm.gamma, nm.beta, y->p, st, (int)x->rows, x->cols, nm.eps, stream));
+    RUNP(SMI_PROF_NORM, 0.0, 4.0 * x->rows * x->cols, launch_layernorm_fwd(dtype, x->p, nm.gamma, nm.beta, y->p, st, (int)x->rows, x->cols, nm.eps, stream));
     y->ng = x->ng;
     if (saving && y->ng) {
       const Norm* np = &nm;
@@ -646,7 +715,7 @@ struct smi_engine {
         if (!y->g) return;
         bool had;
         void* dx = grad_slot(x, had);
-        RUN(launch_layernorm_bwd(dtype, x->p, y->g, np->gamma, st, had ? dx : nullptr, dx, (int)x->rows, x->cols,
+        RUNP(SMI_PROF_NORM, 0.0, 6.0 * x->rows * x->cols, launch_layernorm_bwd(dtype, x->p, y->g, np->gamma, st, had ? dx : nullptr, dx, (int)x->rows, x->cols,
                                  stream));
       });
     }
@@ -660,7 +729,7 @@ struct smi_engine {
     float* mr = alloc_f32((size_t)x->n * G * 2);
     const size_t npart = (size_t)x->n * gn_num_chunks(HW) * G * 2;
     float* part = alloc_f32(npart);
-    RUN(launch_groupnorm_fwd(dtype, x->p, nm.gamma, nm.beta, y->p, ab, mr, part, x->n, HW, C, G, nm.eps, silu ? 1 : 0,
+    RUNP(SMI_PROF_NORM, 0.0, 4.0 * x->rows * x->cols, launch_groupnorm_fwd(dtype, x->p, nm.gamma, nm.beta, y->p, ab, mr, part, x->n, HW, C, G, nm.eps, silu ? 1 : 0,
                              stream));
     y->ng = x->ng;
     if (saving && y->ng) {
@@ -670,7 +739,7 @@ struct smi_engine {
         bool had;
         void* dx = grad_slot(x, had);
         float* scr = alloc_f32(npart + (size_t)2 * x->n * C);
-        RUN(launch_groupnorm_bwd(dtype, x->p, y->g, np->gamma, np->beta, ab, mr, had ? dx : nullptr, dx, scr, x->n, HW,
+        RUNP(SMI_PROF_NORM, 0.0, 6.0 * x->rows * x->cols, launch_groupnorm_bwd(dtype, x->p, y->g, np->gamma, np->beta, ab, mr, had ? dx : nullptr, dx, scr, x->n, HW,
                                  C, G, silu ? 1 : 0, stream));
       });
     }
@@ -680,7 +749,7 @@ struct smi_engine {
   Ten* geglu(Ten* pj) {
     const int C4 = pj->cols / 2;
     Ten* y = new_ten(pj->rows, C4, pj->n, pj->H, pj->W);
-    RUN(launch_geglu_fwd(dtype, pj->p, y->p, (int)pj->rows, C4, stream));
+    RUNP(SMI_PROF_ELEM, 0.0, 6.0 * pj->rows * C4, launch_geglu_fwd(dtype, pj->p, y->p, (int)pj->rows, C4, stream));
     y->ng = pj->ng;
     if (saving && y->ng) {
       tape.push_back([=]() {
@@ -689,10 +758,10 @@ struct smi_engine {
         void* dp = grad_slot(pj, had);
         if (had) {  // never happens in this graph (proj has a single consumer); kept for safety
           void* tmp = alloc_t(pj->rows, pj->cols);
-          RUN(launch_geglu_bwd(dtype, pj->p, y->g, tmp, (int)pj->rows, C4, stream));
-          RUN(launch_add(dtype, dp, tmp, dp, pj->rows * pj->cols, stream));
+          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * pj->rows * C4, launch_geglu_bwd(dtype, pj->p, y->g, tmp, (int)pj->rows, C4, stream));
+          RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dp, tmp, dp, pj->rows * pj->cols, stream));
         } else {
-          RUN(launch_geglu_bwd(dtype, pj->p, y->g, dp, (int)pj->rows, C4, stream));
+          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * pj->rows * C4, launch_geglu_bwd(dtype, pj->p, y->g, dp, (int)pj->rows, C4, stream));
         }
       });
     }
@@ -727,7 +796,7 @@ struct smi_engine {
     p.O = o->p;
     p.ldo = C;
     p.lse = lse;
-    RUN(launch_attn_fwd(p, stream));
+    RUNP(SMI_PROF_ATTN, 4.0 * nbatch * heads * (double)Nq * Nk * p.D, 0.0, launch_attn_fwd(p, stream));
     o->ng = qkv ? qkv->ng : (q->ng || kv->ng);
     if (saving && o->ng) {
       tape.push_back([=]() {
@@ -755,7 +824,7 @@ struct smi_engine {
             b.lddk = b.lddv = 2 * C;
           }
         }
-        RUN(launch_attn_bwd(b, stream));
+        RUNP(SMI_PROF_ATTN, 10.0 * nbatch * heads * (double)Nq * Nk * b.D, 0.0, launch_attn_bwd(b, stream));
       });
     }
     return o;
@@ -794,7 +863,8 @@ struct smi_engine {
       p.res = res->p;
       p.ldr = res->cols;
     }
-    RUN(launch_gemm(p, stream));
+    RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 2.0 * ((double)x->rows * c.Cin + (double)p.N * p.K + (double)p.M * p.N),
+         launch_gemm(p, stream));
     y->ng = x->ng || (res && res->ng);
     if (saving && y->ng) {
       const Conv* cp = &c;
@@ -824,7 +894,7 @@ struct smi_engine {
             b.res = dx;
             b.ldr = cp->Cin;
           }
-          RUN(launch_gemm(b, stream));
+          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
         } else if (cp->mode == 1) {  // gradient of the stride-2 conv: gather dY at (i + 1 - k) / 2
           b.Hin = Hout;
           b.Win = Wout;
@@ -838,20 +908,20 @@ struct smi_engine {
             b.res = dx;
             b.ldr = cp->Cin;
           }
-          RUN(launch_gemm(b, stream));
+          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
         } else {  // upsample + conv: gradient on the 2x grid, then 2x2 sum-pool
           void* du = alloc_t(y->rows, cp->Cin);
           b.Hin = b.Hout = Hout;
           b.Win = b.Wout = Wout;
           b.M = (int)y->rows;
           b.C = du;
-          RUN(launch_gemm(b, stream));
+          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
           if (had) {
             void* tmp = alloc_t(x->rows, cp->Cin);
-            RUN(launch_pool2x2_sum(dtype, du, tmp, x->n, Hin, Win, cp->Cin, stream));
-            RUN(launch_add(dtype, dx, tmp, dx, x->rows * x->cols, stream));
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, tmp, x->n, Hin, Win, cp->Cin, stream));
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dx, tmp, dx, x->rows * x->cols, stream));
           } else {
-            RUN(launch_pool2x2_sum(dtype, du, dx, x->n, Hin, Win, cp->Cin, stream));
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, dx, x->n, Hin, Win, cp->Cin, stream));
           }
         }
       });
@@ -861,8 +931,8 @@ struct smi_engine {
 
   Ten* concat(Ten* a, Ten* b) {
     Ten* y = new_ten(a->rows, a->cols + b->cols, a->n, a->H, a->W);
-    RUN(launch_copy_cols(dtype, a->p, a->cols, y->p, y->cols, 0, (int)a->rows, a->cols, stream));
-    RUN(launch_copy_cols(dtype, b->p, b->cols, y->p, y->cols, a->cols, (int)a->rows, b->cols, stream));
+    RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, a->p, a->cols, y->p, y->cols, 0, (int)a->rows, a->cols, stream));
+    RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, b->p, b->cols, y->p, y->cols, a->cols, (int)a->rows, b->cols, stream));
     y->ng = a->ng || b->ng;
     if (saving && y->ng) {
       tape.push_back([=]() {
@@ -876,11 +946,11 @@ struct smi_engine {
             void* dst = grad_slot(t, had);
             if (had) {
               void* tmp = alloc_t(t->rows, t->cols);
-              RUN(launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, tmp, t->cols, 0, (int)t->rows,
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, tmp, t->cols, 0, (int)t->rows,
                                    t->cols, stream));
-              RUN(launch_add(dtype, dst, tmp, dst, t->rows * t->cols, stream));
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dst, tmp, dst, t->rows * t->cols, stream));
             } else {
-              RUN(launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, dst, t->cols, 0, (int)t->rows,
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, dst, t->cols, 0, (int)t->rows,
                                    t->cols, stream));
             }
           }
@@ -893,7 +963,7 @@ struct smi_engine {
 
   Ten* silu(Ten* x) {  // only used on the (gradient-free) time embedding path
     Ten* y = new_ten(x->rows, x->cols, x->n, x->H, x->W);
-    RUN(launch_silu(dtype, x->p, y->p, x->rows * x->cols, stream));
+    RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_silu(dtype, x->p, y->p, x->rows * x->cols, stream));
     return y;
   }
 
@@ -959,11 +1029,11 @@ struct smi_engine {
       Ten* cat = new_ten(n, cfg.projection_class_embeddings_input_dim);
       Ten pooled;
       pooled.p = const_cast<void*>(text_embeds);
-      RUN(launch_copy_cols(dtype, pooled.p, P, cat->p, cat->cols, 0, n, P, stream));
-      RUN(launch_copy_cols(dtype, tid->p, tid->cols, cat->p, cat->cols, P, n, tid->cols, stream));
+      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, pooled.p, P, cat->p, cat->cols, 0, n, P, stream));
+      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, tid->p, tid->cols, cat->p, cat->cols, P, n, tid->cols, stream));
       Ten* aug = linear(silu(linear(cat, add1)), add2);
       Ten* sum = new_ten(n, ted);
-      RUN(launch_add(dtype, emb->p, aug->p, sum->p, (int64_t)n * ted, stream));
+      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, emb->p, aug->p, sum->p, (int64_t)n * ted, stream));
       emb = sum;
     }
     Ten* temb_act = silu(emb);
@@ -980,7 +1050,7 @@ struct smi_engine {
     Ten* x0 = new_ten((int64_t)n * HW, cfg.in_channels, n, H, Wd_);
     RUN(launch_nchw_to_nhwc(dtype, sample, 1, x0->p, n, cfg.in_channels, HW, cfg.in_channels, 1.f, stream));
     Ten* h = new_ten((int64_t)n * HW, C0, n, H, Wd_);
-    RUN(launch_conv3x3_small(dtype, x0->p, conv_in.Wp, conv_in.b, h->p, 0, n, H, Wd_, cfg.in_channels, C0, stream));
+    RUNP(SMI_PROF_CONV, 0.0, 0.0, launch_conv3x3_small(dtype, x0->p, conv_in.Wp, conv_in.b, h->p, 0, n, H, Wd_, cfg.in_channels, C0, stream));
 
     std::vector<Ten*> skips;
     skips.push_back(h);
@@ -1031,7 +1101,7 @@ struct smi_engine {
       p.Hin = p.Hout = H;
       p.Win = p.Wout = Wd_;
       p.Cin = C0;
-      RUN(launch_gemm(p, stream));
+      RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 0.0, launch_gemm(p, stream));
     }
     RUN(launch_nhwc_to_nchw_f32((const float*)y->p, eps_out, n, cfg.out_channels, HW, stream));
     y->ng = hn->ng;
@@ -1040,7 +1110,7 @@ struct smi_engine {
         if (!y->g) return;
         bool had;
         void* dx = grad_slot(hn, had);
-        RUN(launch_conv3x3_small(dtype, y->g, conv_out.Wg, nullptr, dx, 0, n, H, Wd_, cfg.out_channels, C0, stream));
+        RUNP(SMI_PROF_CONV, 0.0, 0.0, launch_conv3x3_small(dtype, y->g, conv_out.Wg, nullptr, dx, 0, n, H, Wd_, cfg.out_channels, C0, stream));
       });
     }
     if (save) {
@@ -1211,6 +1281,30 @@ int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat
   SMI_CHECK(e && d_eps && d_lora_down_flat && d_lora_up_flat, "NULL argument");
   e->err = false;
   return e->backward(d_eps, d_lora_down_flat, d_lora_up_flat);
+}
+
+int smi_profile_enable(smi_engine* e, int enable) {
+  SMI_CHECK(e != nullptr, "NULL engine");
+  e->prof_collect();
+  e->prof_on = enable != 0;
+  for (int i = 0; i < SMI_PROF_NCAT; ++i) {
+    e->prof_ms[i] = 0;
+    e->prof_flops[i] = 0;
+    e->prof_bytes[i] = 0;
+    e->prof_launches[i] = 0;
+  }
+  return 0;
+}
+int smi_profile_read(smi_engine* e, double* ms, double* flops, double* bytes, int64_t* launches) {
+  SMI_CHECK(e && ms && flops && bytes && launches, "NULL argument");
+  e->prof_collect();
+  for (int i = 0; i < SMI_PROF_NCAT; ++i) {
+    ms[i] = e->prof_ms[i];
+    flops[i] = e->prof_flops[i];
+    bytes[i] = e->prof_bytes[i];
+    launches[i] = e->prof_launches[i];
+  }
+  return 0;
 }
 
 int smi_cfg_combine(const float* eps_2n, float* out_n, int64_t n_half, float g, void* stream) {

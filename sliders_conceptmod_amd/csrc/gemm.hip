@@ -13,6 +13,9 @@
 // row m = (image, oy, ox), K index = (ky, kx, ci).  Cin % 64 == 0 keeps every 64-wide K step inside one filter tap,
 // so the tap geometry is wave-uniform scalar work; padding, tails and strided/transposed/up-sampled taps turn
 // into out-of-range buffer offsets, which the hardware range check returns as zeros.
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.h"
 
 namespace smi {
@@ -286,8 +289,30 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const T* __restrict_
 
 }  // namespace
 
+bool gemm2_supported(const GemmParams& p);
+int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream);
+
+// SMI_GEMM=v1 forces the register-staged kernel, SMI_GEMM=128 / 256 forces a v2 tile height (A/B experiments)
+static int gemm_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SMI_GEMM");
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : 0)));
+  }
+  return mode;
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
   SMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
+  // measured on MI355X (tools/bench_gemm.py): the LDS-DMA kernel wins on dense operands (+5..25 %); for the conv
+  // gather its per-lane 64-bit source addresses cost more VALU than they save, so convs stay on v1 unless forced
+  if (gemm_mode() != 3 && gemm2_supported(p) && (!p.conv || gemm_mode() != 0)) {
+    if (p.conv) {
+      SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
+                "conv: inconsistent geometry");
+    }
+    return launch_gemm2(p, gemm_mode(), stream);
+  }
   SMI_CHECK(p.K % 8 == 0 && p.N % 4 == 0, "gemm: K %% 8 and N %% 4 must be 0 (K=%d N=%d)", p.K, p.N);
   SMI_CHECK(p.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
   SMI_CHECK(p.lora_seg % 4 == 0, "gemm: lora_seg %% 4 != 0");

@@ -1,0 +1,343 @@
+// MFMA GEMM / implicit-GEMM conv, second generation: direct-to-LDS staging.
+//
+// What changed against gemm.hip (kept as the fallback for unaligned operands) and why -- measured on MI355X with
+// rocprofv3 counters on the v1 kernel: MFMA pipe 37 % busy, 22 % of wave-cycles stalled on LDS issue, 0 bank
+// conflicts.  The VGPR->LDS store path (ds_write_b128: 13 cycles per wave-instruction) cost more LDS-pipe time per
+// K-step than the MFMAs take on a 128x128 tile.  Here:
+//   * operands go HBM/L2 -> LDS by LDS-DMA (`global_load_lds_dwordx4`): no staging registers, no ds_write;
+//     the LDS image is lane-linear per wave-instruction (1 KiB = 8 rows x 128 B), so the XOR swizzle that keeps
+//     ds_read_b128 conflict-free is applied to the per-lane SOURCE address (cdna guide rule 21);
+//   * two LDS stages, ONE barrier per K-step: the DMA of tile t+1 is in flight under the MFMAs of tile t;
+//   * rows that do not exist (M/N tails, conv padding, strided / transposed / up-sampled taps) read a 256-byte
+//     zero page instead of relying on the buffer range check (LDS-DMA has a per-lane source address but no
+//     per-lane predicate);
+//   * optional 256-row tile (8 waves) for the large-M layers: fewer LDS bytes staged per FLOP;
+//   * epilogue lane remap: the W-fragment rows of each MFMA pair are permuted so that a lane owns 8 CONSECUTIVE
+//     output columns -> 16-byte stores / residual / bias accesses instead of 8-byte ones.
+#include "kernels.h"
+
+namespace smi {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised
+
+namespace {
+
+constexpr int BN = 128, BK = 64;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+template <typename T, bool CONV, int WM>  // WM wave-rows: block tile = (64*WM) x 128, WM*2 waves
+__global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
+  constexpr int BM = 64 * WM;
+  constexpr int NW = WM * 2;
+  constexpr int STAGE = (BM + BN) * BK * 2;  // bytes
+  constexpr int A_INSTR = (BM / 8) / NW;     // 1-KiB wave-instructions per wave for the A tile (= 4)
+  constexpr int B_INSTR = (BN / 8) / NW;     // (= 4 or 2)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nbn = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int wg;
+  {
+    const int orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int bm0 = (wg / nbn) * BM;
+  const int bn0 = (wg % nbn) * BN;
+
+  const unsigned char* zero = g_zero_page;
+  const T* Ap = reinterpret_cast<const T*>(p.A);
+  const T* Wp = reinterpret_cast<const T*>(p.W);
+
+  // ---- per-lane source rows.  Wave w issues A instructions j = 0..A_INSTR-1 covering tile rows
+  //      (w*A_INSTR + j)*8 + (lane>>3); lane slot (lane&7) holds source chunk slot ^ (row & 7).
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const T* a_ptr[A_INSTR];   // dense: row base pointer (or null -> zero page)
+  int c_base[A_INSTR], c_oy[A_INSTR], c_ox[A_INSTR];
+  int a_chunk[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int row = (wave * A_INSTR + j) * 8 + lrow;
+    const int m = bm0 + row;
+    a_chunk[j] = lslot ^ (row & 7);
+    if (CONV) {
+      if (m < p.M) {
+        const int hw = p.Hout * p.Wout;
+        const int img = m / hw;
+        const int rem = m - img * hw;
+        c_base[j] = img * p.Hin * p.Win;
+        c_oy[j] = rem / p.Wout;
+        c_ox[j] = rem - c_oy[j] * p.Wout;
+      } else {
+        c_base[j] = 0;
+        c_oy[j] = -(1 << 20);
+        c_ox[j] = -(1 << 20);
+      }
+      a_ptr[j] = nullptr;
+    } else {
+      a_ptr[j] = (m < p.M) ? Ap + (int64_t)m * p.lda : nullptr;
+    }
+  }
+  const T* w_ptr[B_INSTR];
+  int w_chunk[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    const int row = (wave * B_INSTR + j) * 8 + lrow;
+    // epilogue lane remap, applied at staging time so fragment reads stay on consecutive (conflict-free) LDS rows:
+    // LDS row 64*wn + 16*ni + fr holds W row 64*wn + 32*(ni>>1) + 8*(fr>>2) + 4*(ni&1) + (fr&3); after the MFMAs
+    // of the pair (2q, 2q+1) a lane then owns the 8 consecutive columns 32q + 8*fq + {0..7}.
+    const int ni_ = (row >> 4) & 3, fr_ = row & 15;
+    const int n = bn0 + (row & 64) + (ni_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (ni_ & 1) + (fr_ & 3);
+    w_chunk[j] = lslot ^ (row & 7);
+    w_ptr[j] = (n < p.N) ? Wp + (int64_t)n * p.K : nullptr;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    unsigned char* As = smem + buf * STAGE;
+    unsigned char* Bs = As + BM * BK * 2;
+    const int k0 = kt * BK;
+    if (CONV) {
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        int iy, ix;
+        bool ok;
+        if (p.transposed) {
+          const int ty = c_oy[j] + 1 - ky, tx = c_ox[j] + 1 - kx;
+          iy = ty / p.stride;
+          ix = tx / p.stride;
+          ok = (ty >= 0) && (tx >= 0) && (iy * p.stride == ty) && (ix * p.stride == tx) && (iy < p.Hin) &&
+               (ix < p.Win);
+        } else {
+          iy = c_oy[j] * p.stride + ky - 1;
+          ix = c_ox[j] * p.stride + kx - 1;
+          if (p.upsample) {
+            ok = (iy >= 0) && (ix >= 0) && (iy < 2 * p.Hin) && (ix < 2 * p.Win);
+            iy >>= 1;
+            ix >>= 1;
+          } else {
+            ok = (iy >= 0) && (ix >= 0) && (iy < p.Hin) && (ix < p.Win);
+          }
+        }
+        const void* src = ok ? (const void*)(Ap + ((int64_t)(c_base[j] + iy * p.Win + ix) * p.Cin + c0 + a_chunk[j] * 8))
+                             : (const void*)zero;
+        glds16(src, As + (wave * A_INSTR + j) * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        const int kc = k0 + a_chunk[j] * 8;
+        const void* src = (a_ptr[j] && kc < p.K) ? (const void*)(a_ptr[j] + kc) : (const void*)zero;
+        glds16(src, As + (wave * A_INSTR + j) * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      const int kc = k0 + w_chunk[j] * 8;
+      const void* src = (w_ptr[j] && kc < p.K) ? (const void*)(w_ptr[j] + kc) : (const void*)zero;
+      glds16(src, Bs + (wave * B_INSTR + j) * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+
+  stage(0, 0);
+  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const unsigned char* As = smem + buf * STAGE;
+    const unsigned char* Bs = As + BM * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      typename TT<T>::v8 xa[4], wb[4];
+      const int ch = kk * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rm = wm * 64 + i * 16 + fr;
+        Pack8<T> t;
+        t.u = *reinterpret_cast<const u32x4*>(As + rm * 128 + ((ch ^ (rm & 7)) << 4));
+        xa[i] = t.v;
+        const int rn = wn * 64 + i * 16 + fr;
+        Pack8<T> s;
+        s.u = *reinterpret_cast<const u32x4*>(Bs + rn * 128 + ((ch ^ (rn & 7)) << 4));
+        wb[i] = s.v;
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = TT<T>::mfma16(wb[ni], xa[mi], acc[ni][mi]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: per (mi, pair q) the lane holds 8 consecutive columns n = nb + 32q + 8fq + {0..7} of row m
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = bm0 + wm * 64 + mi * 16 + fr;
+    if (m >= p.M) continue;
+    const float* xrow0 = p.lora_xa + (int64_t)m * p.ld_xa;
+    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = bn0 + wn * 64 + q * 32 + fq * 8;
+      if (n >= p.N) continue;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[2 * q][mi][j];
+        v[4 + j] = acc[2 * q + 1][mi][j];
+      }
+      const bool full = n + 8 <= p.N;  // N % 8 may be 4 (e.g. conv_out): second half masked
+      if (p.bias) {
+        const T* bp = reinterpret_cast<const T*>(p.bias) + n;
+        if (full) {
+          Pack8<T> b;
+          b.u = *reinterpret_cast<const u32x4*>(bp);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += to_f(b.e[j]);
+        } else {
+          Pack4<T> b;
+          b.u = *reinterpret_cast<const u32x2*>(bp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+        }
+      }
+      if (p.rowvec) {
+        const T* bp = reinterpret_cast<const T*>(p.rowvec) + vrow + n;
+        if (full) {
+          Pack8<T> b;
+          b.u = *reinterpret_cast<const u32x4*>(bp);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += to_f(b.e[j]);
+        } else {
+          Pack4<T> b;
+          b.u = *reinterpret_cast<const u32x2*>(bp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+        }
+      }
+      if (p.lora_r > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (n + j < p.N) {
+            const float* xrow = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
+            const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
+            float d = 0.f;
+            for (int r = 0; r < p.lora_r; ++r) d += xrow[r] * up[r * p.up_sq];
+            v[j] += d * p.lora_scale;
+          }
+        }
+      }
+      if (p.res) {
+        const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n;
+        if (full) {
+          Pack8<T> b;
+          b.u = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += to_f(b.e[j]);
+        } else {
+          Pack4<T> b;
+          b.u = *reinterpret_cast<const u32x2*>(rp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+        }
+      }
+      if (p.out_f32) {
+        float* op = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        if (full) *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        T* op = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
+        if (full) {
+          Pack8<T> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = from_f<T>(v[j]);
+          *reinterpret_cast<u32x4*>(op) = o.u;
+        } else {
+          Pack4<T> o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o.e[j] = from_f<T>(v[j]);
+          *reinterpret_cast<u32x2*>(op) = o.u;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, bool CONV, int WM>
+int launch_t(const GemmParams& p, hipStream_t stream) {
+  constexpr int BM = 64 * WM;
+  constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  static bool attr_done = false;
+  if (!attr_done && SMEM > 65536) {
+    SMI_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, CONV, WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SMEM));
+    attr_done = true;
+  }
+  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM>), dim3(grid), dim3(WM * 128), SMEM, stream, p);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// true when every operand meets the 16-byte alignment / multiple-of-8 layout the LDS-DMA path and the 16-byte
+// epilogue need; anything else goes to the v1 kernel (gemm.hip)
+bool gemm2_supported(const GemmParams& p) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.K % 8 != 0 || !al16(p.A) || !al16(p.W) || !al16(p.C)) return false;
+  if (p.conv ? (p.Cin % 64 != 0) : (p.lda % 8 != 0)) return false;
+  if (p.N % 8 == 0) {
+    if (p.ldc % 8 != 0) return false;
+    if (p.res && (p.ldr % 8 != 0 || !al16(p.res))) return false;
+    if (p.bias && !al16(p.bias)) return false;
+    if (p.rowvec && !al16(p.rowvec)) return false;
+    return true;
+  }
+  return p.N == 4 && p.ldc % 4 == 0 && !p.res && !p.rowvec;  // conv_out: one half-width column group
+}
+
+int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
+  // variant: 0 = auto, 1 = 128-row tile, 2 = 256-row tile
+  int wm = 2;
+  if (variant == 2) wm = 4;
+  else if (variant == 0) {
+    const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, BN);
+    if (tiles256 >= 512) wm = 4;
+  }
+#define GO(TT_, CV, W_) return launch_t<TT_, CV, W_>(p, stream)
+  if (p.dtype == DT_F16) {
+    if (p.conv) { if (wm == 4) GO(f16, true, 4); else GO(f16, true, 2); }
+    else { if (wm == 4) GO(f16, false, 4); else GO(f16, false, 2); }
+  } else {
+    if (p.conv) { if (wm == 4) GO(bf16, true, 4); else GO(bf16, true, 2); }
+    else { if (wm == 4) GO(bf16, false, 4); else GO(bf16, false, 2); }
+  }
+#undef GO
+  return -1;
+}
+
+}  // namespace smi

@@ -46,13 +46,14 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const T* __restrict__ X,
   }
 }
 
-constexpr int WG_ROWS = 512;  // rows of M per workgroup in the weight-gradient reduction
+// rows of M per workgroup in the weight-gradient reduction: small enough that even M = 4096 fills the chip
+__host__ __device__ inline int wg_rows(int M) { return M >= 8192 ? 32 : 16; }
 
 template <typename T, int R>
 __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(const float* __restrict__ P, int64_t ldp,
                                                                  const T* __restrict__ X, int64_t ldx,
                                                                  float* __restrict__ partial, int M, int K, int r) {
-  extern __shared__ float red[];  // [rpar][R][8 * ncols_in_block]
+  extern __shared__ float red[];  // [rpar * ncb][8]
   const int cols8 = K / 8;
   const int colblk = blockIdx.y;  // blocks of up to 256 column vectors
   const int ncb = min(256, cols8 - colblk * 256);
@@ -62,26 +63,33 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(const float* __
   const int cl = tid - rsub * ncb;
   const bool active = rsub < rpar;
   const int col = colblk * 256 + cl;
-  const int row0 = blockIdx.x * WG_ROWS;
-  const int row1 = min(M, row0 + WG_ROWS);
+  const int rows = wg_rows(M);
+  const int row0 = blockIdx.x * rows;
+  const int row1 = min(M, row0 + rows);
   float acc[R][8];
 #pragma unroll
   for (int q = 0; q < R; ++q)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
   if (active) {
-    for (int m = row0 + rsub; m < row1; m += rpar) {
-      Pack8<T> xv;
-      xv.u = *reinterpret_cast<const u32x4*>(X + (int64_t)m * ldx + col * 8);
-      const float* pr = P + (int64_t)m * ldp;
+    // 4 independent row loads in flight per thread (the loop is otherwise a chain of dependent HBM latencies)
+    for (int m0 = row0 + rsub; m0 < row1; m0 += 4 * rpar) {
+      Pack8<T> xv[4];
+      float pv[4][R];
 #pragma unroll
-      for (int q = 0; q < R; ++q) {
-        if (q < r) {
-          const float pq = pr[q];
+      for (int u = 0; u < 4; ++u) {
+        const int m = m0 + u * rpar;
+        const bool ok = m < row1;
+        xv[u].u = ok ? *reinterpret_cast<const u32x4*>(X + (int64_t)m * ldx + col * 8) : u32x4{0, 0, 0, 0};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[q][e] += pq * to_f(xv.e[e]);
-        }
+        for (int q = 0; q < R; ++q) pv[u][q] = (ok && q < r) ? P[(int64_t)m * ldp + q] : 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[q][e] += pv[u][q] * to_f(xv[u].e[e]);
     }
   }
   // combine the rpar row-slices through LDS in a fixed order
@@ -107,7 +115,8 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(const float* __
   }
 }
 
-// dW[q*so_r + k*so_k] += alpha * alpha_dev * sum_s partial[s][q][k]
+// dW[q*so_r + k*so_k] += alpha * alpha_dev * sum_s partial[s][q][k]   (fixed summation order: deterministic)
+// one thread per output element; the nsplit partials of consecutive k are consecutive in memory -> coalesced
 __global__ void lora_wgrad_final_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ dW,
                                         int64_t so_r, int64_t so_k, int K, int r, float alpha,
                                         const float* __restrict__ alpha_dev) {
@@ -116,9 +125,16 @@ __global__ void lora_wgrad_final_kernel(const float* __restrict__ partial, int n
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i / K);
     const int k = (int)(i - (int64_t)q * K);
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += partial[((int64_t)sp * r + q) * K + k];
-    dW[q * so_r + k * so_k] += a * s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 3 < nsplit; sp += 4) {
+      s0 += partial[((int64_t)(sp + 0) * r + q) * K + k];
+      s1 += partial[((int64_t)(sp + 1) * r + q) * K + k];
+      s2 += partial[((int64_t)(sp + 2) * r + q) * K + k];
+      s3 += partial[((int64_t)(sp + 3) * r + q) * K + k];
+    }
+    for (; sp < nsplit; ++sp) s0 += partial[((int64_t)sp * r + q) * K + k];
+    dW[q * so_r + k * so_k] += a * ((s0 + s1) + (s2 + s3));
   }
 }
 
@@ -139,7 +155,7 @@ int down_t(const void* X, int64_t ldx, const float* A, int64_t sr, int64_t sk, f
 template <typename T>
 int wgrad_t(const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r, int64_t so_k, int M, int K, int r,
             float alpha, const float* alpha_dev, float* scratch, hipStream_t st) {
-  const int nsplit = cdiv(M, WG_ROWS);
+  const int nsplit = cdiv(M, wg_rows(M));
   const int cols8 = K / 8;
   dim3 grid(nsplit, cdiv(cols8, 256));
   const size_t sm = 256 * 8 * sizeof(float);
@@ -165,8 +181,8 @@ int launch_lora_down(int dtype, const void* X, int64_t ldx, const float* A, int6
                          : down_t<bf16>(X, ldx, A, lda_r, lda_k, xa, ld_xa, M, K, r, stream);
 }
 
-// scratch: cdiv(M, 512) * r * K floats
-size_t lora_wgrad_scratch_floats(int M, int K, int r) { return (size_t)cdiv(M, WG_ROWS) * r * K; }
+// scratch: lora_wgrad_scratch_floats(M, K, r) floats
+size_t lora_wgrad_scratch_floats(int M, int K, int r) { return (size_t)cdiv(M, wg_rows(M)) * r * K; }
 
 int launch_lora_wgrad(int dtype, const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r,
                       int64_t so_k, int M, int K, int r, float alpha, const float* alpha_dev, float* scratch,

@@ -9,9 +9,10 @@ semantics (inside `with network:` multiplier = 1.0 * lora_scale, after exit 0: l
 `<lora_name>.lora_up.weight [out, r]` (strict-loadable by the reference's eval scripts,
 eval-scripts/generate_images_sd1.py:98-106).
 
-Different underneath: no forward monkey-patching.  All `lora_down` matrices live back to back in ONE flat fp32
-leaf tensor and all `lora_up` matrices in another; the engine reads them by offset, fuses the rank-r delta into the
-GEMM epilogues, and returns the two flat gradients.  `module.lora_down.weight` is a view into the flat tensor.
+Different underneath: no forward monkey-patching.  All parameters live in ONE flat fp32 leaf tensor
+`network.flat = [all lora_down matrices back to back | all lora_up matrices]`; the engine reads them by offset, fuses
+the rank-r delta into the GEMM epilogues, and returns one flat gradient (so the optimiser step, the global-norm clip
+and the data-parallel all-reduce each touch a single buffer).  `module.lora_down.weight` is a view into it.
 Master weights stay fp32 whatever dtype `.to()` asks for (the reference keeps them in the train dtype); files are
 still written in the requested dtype.
 """
@@ -46,6 +47,14 @@ class _WeightView:
         flat = self._owner.flat_down if self._which == "down" else self._owner.flat_up
         n = self._shape[0] * self._shape[1]
         return flat[self._offset:self._offset + n].view(self._shape)
+
+    @property
+    def grad(self) -> Optional[torch.Tensor]:
+        g = self._owner.flat.grad
+        if g is None:
+            return None
+        base = self._offset + (0 if self._which == "down" else self._owner._n_down)
+        return g[base:base + self._shape[0] * self._shape[1]].view(self._shape)
 
 
 class LoRAModule:
@@ -124,8 +133,8 @@ class LoRANetwork(nn.Module):
         targets = select_targets(unet, train_method, target_replace, prefix, delimiter)
         n_down = sum(rank * c.in_features for _, _, c in targets if isinstance(c, nn.Linear))
         n_up = sum(rank * c.out_features for _, _, c in targets if isinstance(c, nn.Linear))
-        self.flat_down = nn.Parameter(torch.zeros(max(n_down, 1), dtype=torch.float32))
-        self.flat_up = nn.Parameter(torch.zeros(max(n_up, 1), dtype=torch.float32))
+        self._n_down, self._n_up = n_down, n_up
+        self.flat = nn.Parameter(torch.zeros(max(n_down + n_up, 1), dtype=torch.float32))
         self.unet_loras: List[LoRAModule] = []
         od = ou = 0
         for lora_name, path, child in targets:
@@ -146,7 +155,14 @@ class LoRANetwork(nn.Module):
                 nn.init.kaiming_uniform_(lora.lora_down.weight, a=1)
         # "apply_to": register with the engine-backed UNet instead of patching module forwards (lora.py:129-132)
         unet.__dict__["_lora_network"] = self  # plain attribute: must not become a registered child module
-        self._n_down, self._n_up = n_down, n_up
+
+    @property
+    def flat_down(self) -> torch.Tensor:
+        return self.flat[:self._n_down]
+
+    @property
+    def flat_up(self) -> torch.Tensor:
+        return self.flat[self._n_down:self._n_down + self._n_up]
 
     # ---- engine side ---------------------------------------------------------------------------------------------
     def engine_sites(self):
@@ -154,19 +170,19 @@ class LoRANetwork(nn.Module):
                  "scale": float(l.scale)} for l in self.unet_loras]
 
     def engine_params(self):
+        """(flat parameter leaf, number of lora_down elements, current multiplier)"""
         mult = self.unet_loras[0].multiplier if self.unet_loras else 0.0
-        return self.flat_down, self.flat_up, float(mult)
+        return self.flat, self._n_down, float(mult)
 
     def _apply(self, fn, *a, **kw):
         super()._apply(fn, *a, **kw)
-        for p in (self.flat_down, self.flat_up):  # fp32 master weights regardless of the requested dtype
-            if p.dtype != torch.float32:
-                p.data = p.data.float()
+        if self.flat.dtype != torch.float32:  # fp32 master weights regardless of the requested dtype
+            self.flat.data = self.flat.data.float()
         return self
 
     # ---- reference API ---------------------------------------------------------------------------------------------
     def prepare_optimizer_params(self):
-        return [{"params": [self.flat_down, self.flat_up]}] if self.unet_loras else []
+        return [{"params": [self.flat]}] if self.unet_loras else []
 
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         sd = OrderedDict() if destination is None else destination

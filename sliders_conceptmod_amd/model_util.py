@@ -1,0 +1,228 @@
+"""Noise schedulers with the interface the reference's helpers call (conceptmod/textsliders/model_util.py:388-436
+builds them; train_util.py:103,287,324,705 and train_lora.py:157-213 use them), plus the model factory.
+
+The scheduler classes of the reference live in diffusers (absent here); these are native restatements of the two the
+slider trainers actually use -- DDIM (eta = 0) and Euler-ancestral -- with the same constants
+(beta 0.00085 -> 0.012 scaled-linear, 1000 train steps, clip_sample False, epsilon prediction).  Coefficients are
+computed on the host in fp32; the latent update runs on the GPU through `smi_sched_step` when the latents are on a
+cuda device."""
+from __future__ import annotations
+
+from typing import Literal
+
+import numpy as np
+import torch
+
+from . import _native
+
+AVAILABLE_SCHEDULERS = Literal["ddim", "ddpm", "lms", "euler_a"]
+
+
+class _StepOutput:
+    def __init__(self, prev_sample):
+        self.prev_sample = prev_sample
+
+
+def _affine(x: torch.Tensor, eps: torch.Tensor, noise, cx: float, ce: float, cn: float) -> torch.Tensor:
+    if x.is_cuda and x.dtype == torch.float32 and eps.dtype == torch.float32:
+        out = x.contiguous().clone()
+        e = eps.contiguous()
+        nz = None if noise is None else noise.to(x.device, torch.float32).contiguous()
+        _native.check(_native.lib().smi_sched_step(_native.ptr(out), _native.ptr(e), _native.ptr(nz), cx, ce, cn,
+                                                   out.numel(), _native.stream_ptr()), "smi_sched_step")
+        return out
+    out = cx * x + ce * eps
+    return out if noise is None else out + cn * noise.to(x.device, x.dtype)
+
+
+def _alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+class DDIMScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000):
+        self.num_train_timesteps = num_train_timesteps
+        self.alphas_cumprod = _alphas_cumprod(num_train_timesteps)
+        self.final_alpha_cumprod = torch.tensor(1.0)
+        self.init_noise_sigma = torch.tensor(1.0)
+        self.num_inference_steps = None
+        self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.int64)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy()
+                                          .astype(np.int64))  # kept on the host: indexing it never syncs the GPU
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None):
+        t = int(timestep)
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else float(self.final_alpha_cumprod)
+        # prev = sqrt(a_prev) * (x - sqrt(1-a_t) eps) / sqrt(a_t) + sqrt(1 - a_prev) eps
+        cx = (a_prev / a_t) ** 0.5
+        ce = (1 - a_prev) ** 0.5 - (a_prev * (1 - a_t) / a_t) ** 0.5
+        return _StepOutput(_affine(sample, model_output, None, cx, ce, 0.0))
+
+    def add_noise(self, original, noise, timesteps):
+        t = torch.as_tensor(timesteps).reshape(-1).long().cpu()
+        sa = (self.alphas_cumprod[t] ** 0.5).to(original.device, original.dtype)
+        sb = ((1 - self.alphas_cumprod[t]) ** 0.5).to(original.device, original.dtype)
+        while sa.ndim < original.ndim:
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * original + sb * noise
+
+
+class EulerAncestralDiscreteScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000):
+        self.num_train_timesteps = num_train_timesteps
+        ac = _alphas_cumprod(num_train_timesteps)
+        self._train_sigmas = (((1 - ac) / ac) ** 0.5).numpy().astype(np.float64)
+        self.sigmas = torch.from_numpy(np.concatenate([self._train_sigmas[::-1], [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(
+            np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy())
+        self.num_inference_steps = None
+
+    @property
+    def init_noise_sigma(self):
+        return self.sigmas.max()
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ts = np.linspace(0, self.num_train_timesteps - 1, num_inference_steps, dtype=np.float32)[::-1].copy()
+        sig = np.interp(ts, np.arange(0, len(self._train_sigmas)), self._train_sigmas)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+
+    def _index(self, timestep) -> int:
+        return int((self.timesteps == float(timestep)).nonzero()[0].item())
+
+    def scale_model_input(self, sample, timestep):
+        sigma = float(self.sigmas[self._index(timestep)])
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output, timestep, sample, generator=None):
+        i = self._index(timestep)
+        sigma, sigma_to = float(self.sigmas[i]), float(self.sigmas[i + 1])
+        sigma_up = (sigma_to ** 2 * (sigma ** 2 - sigma_to ** 2) / sigma ** 2) ** 0.5
+        sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+        # host torch RNG (global generator) keeps the draw order of the reference run: SURVEY.md section 7 "RNG parity"
+        noise = torch.randn(model_output.shape, dtype=torch.float32, generator=generator)
+        # prev = x + eps * (sigma_down - sigma) + noise * sigma_up       (derivative = eps for epsilon prediction)
+        return _StepOutput(_affine(sample, model_output, noise, 1.0, sigma_down - sigma, sigma_up))
+
+    def add_noise(self, original, noise, timesteps):
+        i = self._index(torch.as_tensor(timesteps).reshape(-1)[0])
+        return original + noise * float(self.sigmas[i])
+
+
+def create_noise_scheduler(scheduler_name: AVAILABLE_SCHEDULERS = "ddpm", prediction_type="epsilon"):
+    name = scheduler_name.lower().replace(" ", "_")
+    if prediction_type != "epsilon":
+        raise ValueError("only epsilon prediction is built (v_pred models: SD-2.x are outside this tier)")
+    if name == "ddim":
+        return DDIMScheduler()
+    if name == "euler_a":
+        return EulerAncestralDiscreteScheduler()
+    if name in ("ddpm", "lms"):
+        raise ValueError(f"scheduler '{name}' is not built natively; the slider configs use ddim / euler_a")
+    raise ValueError(f"Unknown scheduler name: {name}")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# model factory (reference: conceptmod/textsliders/model_util.py:27-137, 170-385 -- hub / checkpoint loaders)
+# ----------------------------------------------------------------------------------------------------------------
+class SyntheticTextEncoder:
+    """Offline stand-in for tokenizer + CLIP text encoder(s): a prompt maps to seeded normal embeddings
+    ([1, 77, D] and, for SD-XL, a pooled [1, P]) keyed by a hash of the text, so equal prompts share embeddings
+    exactly as the reference's PromptEmbedsCache assumes (train_lora.py:106-146).  The real front end (CLIP-L /
+    OpenCLIP-bigG) is a 'next' row of the scope table."""
+
+    def __init__(self, dim: int, pooled_dim: int = 0, seq_len: int = 77):
+        self.dim, self.pooled_dim, self.seq_len = dim, pooled_dim, seq_len
+
+    def encode(self, prompt: str):
+        import hashlib
+        seed = int.from_bytes(hashlib.sha256(prompt.encode()).digest()[:8], "little") % (2 ** 31)
+        g = torch.Generator().manual_seed(seed)
+        te = torch.randn(1, self.seq_len, self.dim, generator=g)
+        if self.pooled_dim:
+            return te, torch.randn(1, self.pooled_dim, generator=g)
+        return te
+
+
+def _unet_from_dir(path: str, dtype):
+    """diffusers directory layout: <path>/unet/config.json + diffusion_pytorch_model.safetensors (safe loader only)."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from . import unet as PU
+    cfgj = json.load(open(os.path.join(path, "unet", "config.json")))
+    ahd = cfgj.get("attention_head_dim", 8)
+    n = len(cfgj["block_out_channels"])
+    tl = cfgj.get("transformer_layers_per_block", 1)
+    cfg = PU.UNetConfig(
+        in_channels=cfgj.get("in_channels", 4), out_channels=cfgj.get("out_channels", 4),
+        block_out_channels=tuple(cfgj["block_out_channels"]), down_block_types=tuple(cfgj["down_block_types"]),
+        up_block_types=tuple(cfgj["up_block_types"]), layers_per_block=cfgj.get("layers_per_block", 2),
+        transformer_layers_per_block=tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * n,
+        num_attention_heads=tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * n,
+        cross_attention_dim=cfgj["cross_attention_dim"], norm_num_groups=cfgj.get("norm_num_groups", 32),
+        use_linear_projection=cfgj.get("use_linear_projection", False),
+        addition_embed_type=cfgj.get("addition_embed_type"),
+        addition_time_embed_dim=cfgj.get("addition_time_embed_dim") or 256,
+        projection_class_embeddings_input_dim=cfgj.get("projection_class_embeddings_input_dim") or 2816)
+    unet = PU.UNet2DConditionModel(cfg)
+    sd = load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors"))
+    unet.load_state_dict(sd)
+    return unet
+
+
+def load_models(pretrained_model_name_or_path: str, scheduler_name: str = "ddim", v2: bool = False,
+                v_pred: bool = False, weight_dtype=torch.float32, xl: bool = False):
+    """Returns (tokenizer(s), text_encoder(s), unet, noise_scheduler) like the reference (model_util.py:112-137,
+    :359-385).  `synthetic://sd1x|sdxl|tiny_sd1x|tiny_sdxl` builds the architecture with seeded random weights (no
+    network here).  A local diffusers directory is loaded with safetensors; its text encoders through `transformers`."""
+    from . import unet as PU
+    if v2 or v_pred:
+        raise ValueError("SD-2.x / v-prediction models are outside this tier (epsilon-prediction SD-1.x / SD-XL only)")
+    scheduler = create_noise_scheduler(scheduler_name)
+    name = pretrained_model_name_or_path
+    if name.startswith("synthetic://"):
+        kind = name[len("synthetic://"):]
+        tiny = {"tiny_sd1x": PU.UNetConfig(block_out_channels=(64, 128, 256, 256), num_attention_heads=(4, 4, 4, 4),
+                                           cross_attention_dim=64, norm_num_groups=16),
+                "tiny_sdxl": PU.UNetConfig(
+                    block_out_channels=(64, 128, 256),
+                    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                    transformer_layers_per_block=(1, 2, 3), num_attention_heads=(2, 4, 8), cross_attention_dim=64,
+                    norm_num_groups=16, use_linear_projection=True, addition_embed_type="text_time",
+                    addition_time_embed_dim=32, projection_class_embeddings_input_dim=256)}
+        cfg = {"sd1x": PU.sd1x_config, "sdxl": PU.sdxl_config}.get(kind, lambda: tiny[kind])()
+        unet = PU.init_synthetic_(PU.UNet2DConditionModel(cfg), seed=0)
+        pooled = 0
+        if cfg.addition_embed_type == "text_time":
+            pooled = cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim
+        enc = SyntheticTextEncoder(cfg.cross_attention_dim, pooled)
+        return None, enc, unet, scheduler
+    import os
+    if os.path.isdir(name):
+        unet = _unet_from_dir(name, weight_dtype)
+        from transformers import CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer
+        toks = [CLIPTokenizer.from_pretrained(name, subfolder="tokenizer")]
+        encs = [CLIPTextModel.from_pretrained(name, subfolder="text_encoder")]
+        if os.path.isdir(os.path.join(name, "text_encoder_2")):
+            toks.append(CLIPTokenizer.from_pretrained(name, subfolder="tokenizer_2"))
+            encs.append(CLIPTextModelWithProjection.from_pretrained(name, subfolder="text_encoder_2"))
+        return toks, encs, unet, scheduler
+    raise ValueError(f"cannot load '{name}': no network in this environment; pass a local diffusers directory or "
+                     f"synthetic://sd1x | synthetic://sdxl")

@@ -1,0 +1,131 @@
+"""The slider train step as one device-side sequence: 3 frozen UNet passes + 1 adapted pass + guidance loss +
+backward + (all-reduce) + global-norm clip + AdamW, without a host sync and without autograd graph construction.
+
+It is the same arithmetic, in the same order, as the reference loop body (conceptmod/textsliders/train_lora.py:
+216-300 for SD-1.x; train_lora_xl.py:240-351 for SD-XL) -- the drop-in helpers in train_util.py + torch autograd give
+identical results and stay available; this class only removes Python/autograd overhead from the hot loop:
+
+    positive / neutral / negative|unconditional : predict_noise(_xl) with the adaptor off     (train_lora.py:216-252)
+    target                                      : predict_noise(_xl) inside `with network`     (train_lora.py:261-273)
+    loss = PromptEmbedsPair.loss(...)                                                          (prompt_util.py:134-174)
+    loss.backward(); [clip_grad_norm_(0.2)]; optimizer.step()                    (train_lora_xl.py:348-350)
+
+Data parallelism (no reference counterpart): each rank runs the step on its shard of the batch; the flat fp32
+LoRA gradient is all-reduced (RCCL, sum / world) after backward and BEFORE the clip, so the clip sees the
+global-batch gradient exactly as a single-GPU run of the global batch would."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _native
+
+
+class SliderStep:
+    def __init__(self, unet, network, scheduler, *, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, max_grad_norm: float = 0.0, cfg_scale: float = 1.0,
+                 skip_dead_cfg_half: bool = False, process_group=None):
+        self.unet, self.network, self.scheduler = unet, network, scheduler
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.cfg_scale = cfg_scale
+        # With CFG scale 1 the unconditional half of the doubled batch is algebraically dead (u + 1*(t-u) == t).
+        # Off by default: the reference computes it, so the headline number does too.
+        self.skip_dead = bool(skip_dead_cfg_half and cfg_scale == 1.0)
+        self.pg = process_group
+        flat = network.flat
+        self.grad = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.scratch = torch.empty(4096, dtype=torch.float32, device=flat.device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.step_count = 0
+        self._lib = _native.lib()
+
+    # ---- conditioning for one prompt pair, laid out as the reference's concat_embeddings does (train_util.py:267-272)
+    def make_conditioning(self, emb: Dict[str, torch.Tensor], batch_size: int, pooled: Optional[dict] = None,
+                          time_ids: Optional[torch.Tensor] = None) -> dict:
+        dt, dev = self.unet.dtype, self.unet.device
+        sub = "negative" if "negative" in emb else "unconditional"
+        out = {"B": batch_size, "keys": {"positive": "positive", "neutral": "neutral", "negative": sub,
+                                         "target": "target"}}
+        for role, key in out["keys"].items():
+            if self.skip_dead:
+                te = emb[key].repeat_interleave(batch_size, dim=0)
+            else:
+                te = torch.cat([emb["unconditional"], emb[key]]).repeat_interleave(batch_size, dim=0)
+            c = {"ctx": te.to(dev, dt).contiguous()}
+            if pooled is not None:
+                if self.skip_dead:
+                    pe = pooled[key].repeat_interleave(batch_size, dim=0)
+                    ti = time_ids.repeat_interleave(batch_size, dim=0)
+                else:
+                    pe = torch.cat([pooled["unconditional"], pooled[key]]).repeat_interleave(batch_size, dim=0)
+                    ti = torch.cat([time_ids, time_ids]).repeat_interleave(batch_size, dim=0)
+                c["text_embeds"] = pe.to(dev, dt).contiguous()
+                c["time_ids"] = ti.to(dev, torch.float32).contiguous()
+            out[role] = c
+        return out
+
+    def _pass(self, engine, x, t, c, lora: bool, save: bool):
+        flat, n_down, mult = self.network.engine_params()
+        down = up = None
+        if lora:
+            down, up = flat[:n_down], flat[n_down:]
+        eps = engine.forward(x, t, c["ctx"], c.get("text_embeds"), c.get("time_ids"), down, up,
+                             mult if lora else 0.0, save)
+        if self.skip_dead:
+            return eps
+        out = torch.empty((eps.shape[0] // 2,) + tuple(eps.shape[1:]), dtype=torch.float32, device=eps.device)
+        _native.check(self._lib.smi_cfg_combine(_native.ptr(eps), _native.ptr(out), out.numel(), self.cfg_scale,
+                                                _native.stream_ptr()), "smi_cfg_combine")
+        return out
+
+    def train_step(self, denoised_latents: torch.Tensor, timestep, cond: dict, action: str, eta: float,
+                   lr: Optional[float] = None) -> torch.Tensor:
+        """One optimisation step; returns the loss as a 1-element device tensor (no host sync)."""
+        lat = denoised_latents.float()
+        x = lat if self.skip_dead else torch.cat([lat] * 2)
+        x = self.scheduler.scale_model_input(x, timestep).contiguous()
+        t = float(timestep)
+        n, _, h, w = x.shape
+        engine = self.unet._ensure_engine(n, h, w, cond["target"]["ctx"].shape[1])
+        net = self.network
+        net.__exit__(None, None, None)
+        positive = self._pass(engine, x, t, cond["positive"], False, False)
+        neutral = self._pass(engine, x, t, cond["neutral"], False, False)
+        negative = self._pass(engine, x, t, cond["negative"], False, False)
+        net.__enter__()
+        target = self._pass(engine, x, t, cond["target"], True, True)
+        net.__exit__(None, None, None)
+
+        sign_eta = eta if action == "enhance" else -eta
+        if action not in ("enhance", "erase"):
+            raise ValueError("action must be erase or enhance")
+        dtarget = torch.empty_like(target)
+        _native.check(self._lib.smi_slider_loss(_native.ptr(target), _native.ptr(positive), _native.ptr(neutral),
+                                                _native.ptr(negative), sign_eta, target.numel(),
+                                                _native.ptr(self.loss), _native.ptr(dtarget),
+                                                _native.ptr(self.scratch), _native.stream_ptr()), "smi_slider_loss")
+        if self.skip_dead:
+            d_eps = dtarget
+        else:  # d(u + g (t - u)) = (1 - g) du + g dt
+            d_eps = torch.cat([dtarget * (1.0 - self.cfg_scale), dtarget * self.cfg_scale])
+        self.grad.zero_()
+        n_down = net._n_down
+        engine.backward(d_eps, self.grad[:n_down], self.grad[n_down:])
+        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                   and torch.distributed.get_world_size() > 1):
+            torch.distributed.all_reduce(self.grad, group=self.pg)
+            self.grad.div_(torch.distributed.get_world_size(self.pg))
+            torch.distributed.all_reduce(self.loss, group=self.pg)
+            self.loss.div_(torch.distributed.get_world_size(self.pg))
+        self.step_count += 1
+        flat = net.flat
+        _native.check(self._lib.smi_clip_adamw(_native.ptr(flat), _native.ptr(self.grad), _native.ptr(self.exp_avg),
+                                               _native.ptr(self.exp_avg_sq), flat.numel(),
+                                               self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
+                                               self.weight_decay, self.step_count, self.max_grad_norm,
+                                               _native.ptr(self.scratch), _native.stream_ptr()), "smi_clip_adamw")
+        return self.loss

@@ -201,22 +201,25 @@ class _UNetFn(torch.autograd.Function):
     """Autograd bookkeeping only: forward and backward are single calls into the HIP engine."""
 
     @staticmethod
-    def forward(ctx, save, engine, sample, timestep, ehs, text_embeds, time_ids, flat_down, flat_up, multiplier):
+    def forward(ctx, save, engine, sample, timestep, ehs, text_embeds, time_ids, flat, n_down, multiplier):
         # `save` is decided by the caller: grad mode is always off inside Function.forward
-        eps = engine.forward(sample, timestep, ehs, text_embeds, time_ids, flat_down, flat_up, multiplier, save)
+        down = up = None
+        if flat is not None:
+            down, up = flat[:n_down], flat[n_down:]
+        eps = engine.forward(sample, timestep, ehs, text_embeds, time_ids, down, up, multiplier, save)
         ctx.engine = engine if save else None
-        ctx.keep = (sample, ehs, text_embeds, time_ids, flat_down, flat_up)  # borrowed by the engine until backward
+        ctx.n_down = n_down
+        ctx.keep = (sample, ehs, text_embeds, time_ids, flat)  # borrowed by the engine until backward
         return eps
 
     @staticmethod
     def backward(ctx, d_eps):
         if ctx.engine is None:
             return (None,) * 10
-        flat_down, flat_up = ctx.keep[4], ctx.keep[5]
-        gd = torch.zeros_like(flat_down)
-        gu = torch.zeros_like(flat_up)
-        ctx.engine.backward(d_eps.contiguous().float(), gd, gu)
-        return None, None, None, None, None, None, None, gd, gu, None
+        flat = ctx.keep[4]
+        g = torch.zeros_like(flat)
+        ctx.engine.backward(d_eps.contiguous().float(), g[:ctx.n_down], g[ctx.n_down:])
+        return None, None, None, None, None, None, None, g, None, None
 
 
 class UNet2DConditionModel(nn.Module):
@@ -305,12 +308,11 @@ class UNet2DConditionModel(nn.Module):
             time_ids = added_cond_kwargs["time_ids"].float().contiguous()
         t = float(timestep)
         net = self._lora_network
-        flat_down = flat_up = None
-        mult = 0.0
+        flat, n_down, mult = None, 0, 0.0
         if net is not None:
-            flat_down, flat_up, mult = net.engine_params()
-        save = bool(torch.is_grad_enabled() and mult != 0 and flat_down is not None and flat_down.requires_grad)
-        eps = _UNetFn.apply(save, eng, sample.float().contiguous(), t, ehs, text_embeds, time_ids, flat_down, flat_up,
+            flat, n_down, mult = net.engine_params()
+        save = bool(torch.is_grad_enabled() and mult != 0 and flat is not None and flat.requires_grad)
+        eps = _UNetFn.apply(save, eng, sample.float().contiguous(), t, ehs, text_embeds, time_ids, flat, n_down,
                             float(mult))
         return UNetOutput(eps)
 

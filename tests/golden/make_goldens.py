@@ -217,7 +217,7 @@ def main():
             opt = ref_tu.get_optimizer("AdamW")(net.prepare_optimizer_params(), lr=2e-3)
             lrs = ref_tu.get_lr_scheduler("constant", opt, max_iterations=8, lr_min=2e-5)
         else:
-            opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-6)
+            opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6)  # hard-coded, train_lora_xl.py:104
             lrs = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50, eta_min=1e-6)
         s = _S()
         s.action = "enhance"
@@ -226,7 +226,8 @@ def main():
         pair = ref_pu.PromptEmbedsPair(torch.nn.MSELoss(), None, None, None, None, None, s)
         max_steps = 8
         losses = []
-        torch.manual_seed(99)
+        # NOTE: no reseed here -- the loop continues the global RNG stream left by the LoRA init (seed 1 above),
+        # exactly as a real run of the reference script does; the product's train() is checked against this.
         for it in range(6):
             with torch.no_grad():
                 sched.set_timesteps(max_steps)
@@ -285,8 +286,8 @@ def main():
         manifest[f"traj/{model}"] = {
             "losses": losses, "iterations": 6, "max_denoising_steps": max_steps,
             "norms": {k: float(v.float().norm()) for k, v in sd.items()},
-            "seeds": {"loop": 99, "lora_init": 1, "unet": 0, "emb": 4},
-            "optimizer": "AdamW lr 2e-3 constant" if not xl else "AdamW lr 1e-3 wd 1e-6 cosine(50,1e-6) clip 0.2",
+            "seeds": {"lora_init_then_loop": 1, "unet": 0, "emb": 4},
+            "optimizer": "AdamW lr 2e-3 constant" if not xl else "AdamW lr 1e-4 wd 1e-6 cosine(50,1e-6) clip 0.2",
         }
 
     # ------------------------------------------------------------------ (6) helpers: add_time_ids, LR traces, config

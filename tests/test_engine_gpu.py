@@ -114,12 +114,8 @@ def test_lora_gradients_match_oracle(model, dtype, method):
         got = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
     assert got.requires_grad
     (got * gy.cuda()).sum().backward()
-    assert pnet.flat_down.grad is not None and pnet.flat_up.grad is not None
-    sd_g = {}
-    for l in pnet.unet_loras:
-        n_d, n_u = l.lora_dim * l.in_dim, l.lora_dim * l.out_dim
-        sd_g[l.lora_name] = (pnet.flat_down.grad[l.off_down:l.off_down + n_d].view(l.lora_dim, l.in_dim),
-                             pnet.flat_up.grad[l.off_up:l.off_up + n_u].view(l.out_dim, l.lora_dim))
+    assert pnet.flat.grad is not None
+    sd_g = {l.lora_name: (l.lora_down.grad, l.lora_up.grad) for l in pnet.unet_loras}
     tol = 2.5e-2 if dtype == torch.float16 else 1.2e-1  # per-module gradient, 16-bit activation gradients
     worst = 0.0
     tot_num = tot_den = 0.0
@@ -146,16 +142,15 @@ def test_interleaved_frozen_pass_does_not_clobber_tape(dtype):
     with pnet:
         a = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda()).sample
     (a * gy).sum().backward()
-    g1 = pnet.flat_up.grad.clone()
-    pnet.flat_up.grad = None
-    pnet.flat_down.grad = None
+    g1 = pnet.flat.grad.clone()
+    pnet.flat.grad = None
     with pnet:
         b = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda()).sample
     with torch.no_grad():
         pnet.__exit__(None, None, None)
         pu(x.cuda() * 0.5, 20.0, encoder_hidden_states=ctx.cuda() * 2).sample
     (b * gy).sum().backward()
-    torch.testing.assert_close(pnet.flat_up.grad, g1, rtol=0, atol=0)  # deterministic kernels: bitwise equal
+    torch.testing.assert_close(pnet.flat.grad, g1, rtol=0, atol=0)  # deterministic kernels: bitwise equal
 
 
 def test_smaller_batch_than_engine_capacity():

@@ -81,7 +81,7 @@ def test_lora_init_is_seed_compatible_with_reference(goldens, model):
     assert len(keys) == 2
     for k in keys:
         torch.testing.assert_close(sd[k.split("/init/")[1]], t[k], rtol=0, atol=0)
-    assert float(net.flat_up.detach().abs().max()) == 0.0
+    assert float(net.flat_up.detach().abs().max()) == 0.0 and net.flat.is_leaf
 
 
 def test_context_manager_and_slider_semantics():
@@ -95,7 +95,7 @@ def test_context_manager_and_slider_semantics():
     net.set_lora_slider(-2.5)
     with net:
         assert net.engine_params()[2] == -2.5
-    assert net.prepare_optimizer_params()[0]["params"][0] is net.flat_down
+    assert net.prepare_optimizer_params()[0]["params"][0] is net.flat
     assert net.unet_loras[0].scale == 0.25
 
 
@@ -104,6 +104,7 @@ def test_save_and_strict_reload(tmp_path):
     net = L.LoRANetwork(unet, rank=4, alpha=1.0, train_method="noxattn")
     with torch.no_grad():
         net.flat_up.normal_(0, 0.1)
+    assert float(net.flat.detach()[net._n_down:].abs().max()) > 0  # flat_up is a live view of the single leaf
     for ext in (".pt", ".safetensors"):
         f = tmp_path / f"w{ext}"
         net.save_weights(f, dtype=torch.bfloat16)
@@ -121,7 +122,7 @@ def test_save_and_strict_reload(tmp_path):
         with pytest.raises(RuntimeError):
             net2.load_state_dict(bad)
     net.to(dtype=torch.bfloat16)  # reference does .to(device, dtype=weight_dtype); master weights stay fp32
-    assert net.flat_down.dtype == torch.float32
+    assert net.flat.dtype == torch.float32
 
 
 def test_unet_without_gpu_fails_loudly():

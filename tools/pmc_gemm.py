@@ -1,0 +1,13 @@
+import ctypes as C, sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sliders_conceptmod_amd import _native
+lib = _native.lib()
+P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+for (M, N, K, epi) in [(4096, 4096, 4096, 0), (16384, 5120, 640, 1), (4096, 1280, 1280, 1)]:
+    a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+    c = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    bias = torch.randn(N, device="cuda").half() if epi else None
+    res = torch.randn(M, N, device="cuda").half() if epi else None
+    for _ in range(3):
+        lib.smi_op_gemm(0, P(a), P(w), P(c), M, N, K, P(bias), P(res), None, None, 0, 0.0, 0, None)
+    torch.cuda.synchronize()
