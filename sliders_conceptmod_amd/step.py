@@ -19,7 +19,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import _native
+from . import _native, parallel
 
 
 class SliderStep:
@@ -115,12 +115,8 @@ class SliderStep:
         self.grad.zero_()
         n_down = net._n_down
         engine.backward(d_eps, self.grad[:n_down], self.grad[n_down:])
-        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                   and torch.distributed.get_world_size() > 1):
-            torch.distributed.all_reduce(self.grad, group=self.pg)
-            self.grad.div_(torch.distributed.get_world_size(self.pg))
-            torch.distributed.all_reduce(self.loss, group=self.pg)
-            self.loss.div_(torch.distributed.get_world_size(self.pg))
+        parallel.allreduce_mean_(self.grad, self.pg)  # no-op on a single rank
+        parallel.allreduce_mean_(self.loss, self.pg)
         self.step_count += 1
         flat = net.flat
         _native.check(self._lib.smi_clip_adamw(_native.ptr(flat), _native.ptr(self.grad), _native.ptr(self.exp_avg),

@@ -16,7 +16,7 @@ from pathlib import Path
 import torch
 from tqdm import tqdm
 
-from . import config_util, model_util, prompt_util, train_util
+from . import config_util, model_util, parallel, prompt_util, train_util
 from .config_util import RootConfig
 from .lora import DEFAULT_TARGET_REPLACE, LoRANetwork
 from .prompt_util import PromptEmbedsCache, PromptEmbedsPair, PromptSettings
@@ -89,9 +89,8 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
             bs = prompt_pair.batch_size
             latents = train_util.get_initial_latents(noise_scheduler, bs, height, width, 1)
             if world > 1:
-                assert bs % world == 0, "batch_size must divide by the number of ranks"
+                latents = latents[parallel.shard_slice(bs, rank, world)]
                 bs = bs // world
-                latents = latents[rank * bs:(rank + 1) * bs]
             latents = latents.to(device, dtype=torch.float32)
             with network:
                 denoised_latents = train_util.diffusion(
@@ -119,8 +118,7 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
         pbar.set_description(f"Loss*1k: {loss.item() * 1000:.4f}")
         loss.backward()
         if world > 1:  # mean over ranks == the gradient of the global-batch MSE
-            torch.distributed.all_reduce(network.flat.grad)
-            network.flat.grad.div_(world)
+            parallel.allreduce_mean_(network.flat.grad)
         optimizer.step()
         lr_scheduler.step()
         if on_step_complete is not None:

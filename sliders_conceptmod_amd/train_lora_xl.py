@@ -14,7 +14,7 @@ from pathlib import Path
 import torch
 from tqdm import tqdm
 
-from . import config_util, model_util, prompt_util, train_util
+from . import config_util, model_util, parallel, prompt_util, train_util
 from .config_util import RootConfig
 from .lora import LoRANetwork
 from .prompt_util import PromptEmbedsCache, PromptEmbedsPair, PromptEmbedsXL
@@ -88,9 +88,8 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
             bs = prompt_pair.batch_size
             latents = train_util.get_initial_latents(noise_scheduler, bs, height, width, 1)
             if world > 1:
-                assert bs % world == 0, "batch_size must divide by the number of ranks"
+                latents = latents[parallel.shard_slice(bs, rank_, world)]
                 bs = bs // world
-                latents = latents[rank_ * bs:(rank_ + 1) * bs]
             latents = latents.to(device, dtype=torch.float32)
             add_time_ids = train_util.get_add_time_ids(height, width, dynamic_crops=prompt_pair.dynamic_crops,
                                                        dtype=torch.float32).to(device)
