@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const T* __restrict
 //                               -> gradient pack dst[ci][(ty*3+tx)*Cout + co] = w[co][ci][ky][kx],
 //                                  (ty,tx) = flip ? (2-ky, 2-kx) : (ky, kx)
 template <typename T>
-__global__ void pack_conv_kernel(const T* __restrict__ src, T* __restrict__ dst, int Cout, int Cin, int mode) {
+__global__ void pack_conv_kernel(const T* __restrict__ src, T* __restrict__ dst, int Cout, int Cin, int mode,
+                                 int pad) {  // pad: padded inner channel count (Cin for mode 0, Cout otherwise)
   const int64_t total = (int64_t)Cout * Cin * 9;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int t = (int)(i % 9);
@@ -76,10 +77,10 @@ __global__ void pack_conv_kernel(const T* __restrict__ src, T* __restrict__ dst,
     const int co = (int)(i / (9 * (int64_t)Cin));
     const int ky = t / 3, kx = t % 3;
     if (mode == 0) {
-      dst[((int64_t)co * 9 + t) * Cin + ci] = src[i];
+      dst[((int64_t)co * 9 + t) * pad + ci] = src[i];
     } else {
       const int tt = mode == 2 ? (2 - ky) * 3 + (2 - kx) : t;
-      dst[((int64_t)ci * 9 + tt) * Cout + co] = src[i];
+      dst[((int64_t)ci * 9 + tt) * pad + co] = src[i];
     }
   }
 }
@@ -126,6 +127,10 @@ struct Lin {
   int rank = 0;
   float scale = 0.f;
   int64_t off_down = 0, off_up = 0;
+  // 16-bit GEMM-operand copies of the LoRA matrices, refreshed once per adapted forward (lora.hip lora_prep_kernel)
+  int rows_pad = 0;
+  const void* sh_down = nullptr;  // [rows_pad, in]
+  const void* sh_up = nullptr;    // [rows_pad, out] block-diagonal over the fused segments
 };
 struct Conv {
   const void* Wp = nullptr;   // forward pack [Cout][9*Cin]
@@ -149,6 +154,7 @@ struct Resnet {
 struct TBlock {
   Norm n1, n2, n3;
   Lin qkv1, out1, q2, kv2, out2, ff1, ff2;
+  int64_t kv_col = 0;  // column offset of this block's k|v inside the grouped projection
 };
 struct Transformer {
   Norm norm;
@@ -190,6 +196,16 @@ struct smi_engine {
   std::vector<smi_lora_site> sites;
   std::vector<std::string> site_names;
   std::vector<char> site_used;
+
+  // LoRA shadow operands
+  std::vector<HostLoraPrepSite> prep_sites;
+  void* prep_sites_dev = nullptr;
+  char* lora_shadow = nullptr;
+  size_t lora_shadow_elems = 0;
+  // grouped cross-attention K|V projection: every block's to_k|to_v stacked into one [sum N, D_ctx] matrix
+  Lin kv_all;
+  bool kv_grouped = false;
+  Ten* kv_all_out = nullptr;
 
   // model
   Conv conv_in, conv_out;
@@ -367,14 +383,16 @@ struct smi_engine {
     else
       hipLaunchKernelGGL(pack_transpose_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, R, C, ldd, col0);
   }
-  void pack_conv_into(const void* src, void* dst, int Cout, int Cin, int mode) {
+  void pack_conv_into(const void* src, void* dst, int Cout, int Cin, int mode, int pad = 0) {
     if (dry || err || !src) return;
+    if (pad == 0) pad = mode == 0 ? Cin : Cout;
+    else (void)hipMemsetAsync(dst, 0, (size_t)(mode == 0 ? Cout : Cin) * 9 * pad * esz(), stream);
     const int64_t total = (int64_t)Cout * Cin * 9;
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
     if (dtype == DT_F16)
-      hipLaunchKernelGGL(pack_conv_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, Cout, Cin, mode);
+      hipLaunchKernelGGL(pack_conv_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, Cout, Cin, mode, pad);
     else
-      hipLaunchKernelGGL(pack_conv_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, Cout, Cin, mode);
+      hipLaunchKernelGGL(pack_conv_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, Cout, Cin, mode, pad);
   }
 
   void attach_lora(Lin& L, const std::vector<std::string>& targets) {
@@ -410,7 +428,32 @@ struct smi_engine {
     L.scale = first->scale;
     L.off_down = first->off_down;
     L.off_up = first->off_up;
+    const int rtot = L.rank * L.nseg;
+    L.rows_pad = (rtot + 15) / 16 * 16;
+    HostLoraPrepSite ps;
+    ps.off_down = L.off_down;
+    ps.off_up = L.off_up;
+    ps.dst_down = (int64_t)lora_shadow_elems;
+    lora_shadow_elems += (size_t)L.rows_pad * L.in;
+    ps.dst_up = (int64_t)lora_shadow_elems;
+    lora_shadow_elems += (size_t)L.rows_pad * L.out;
+    ps.r = L.rank;
+    ps.nseg = L.nseg;
+    ps.K = L.in;
+    ps.cs = L.out / L.nseg;
+    ps.rows_pad = L.rows_pad;
+    prep_sites.push_back(ps);
+    L.sh_down = reinterpret_cast<const void*>((uintptr_t)ps.dst_down);  // offsets for now; rebased in finish_lora()
+    L.sh_up = reinterpret_cast<const void*>((uintptr_t)ps.dst_up);
   }
+  void finish_lora() {  // after build(): all Lin objects are at their final addresses
+    lora_shadow = (char*)pack_alloc(std::max<size_t>(lora_shadow_elems, 8) * esz());
+    prep_sites_dev = pack_alloc(std::max<size_t>(prep_sites.size(), 1) * sizeof(HostLoraPrepSite));
+    if (!dry && !err && !prep_sites.empty())
+      (void)hipMemcpyAsync(prep_sites_dev, prep_sites.data(), prep_sites.size() * sizeof(HostLoraPrepSite),
+                           hipMemcpyHostToDevice, stream);
+  }
+  const void* shadow_ptr(const void* off) const { return lora_shadow + (uintptr_t)off * 2; }
 
   // need_t: the layer lies on the gradient path (gets a transposed copy) and may carry a LoRA adaptor
   Lin make_lin(const std::string& name, int in, int out, bool bias, bool need_t = true) {
@@ -522,7 +565,15 @@ struct smi_engine {
     const int* boc = cfg.block_out_channels;
     const int ted = boc[0] * 4;
     // conv_in: direct small-Cin kernel, weights (ky,kx,ci)-ordered
-    conv_in = make_conv("conv_in", cfg.in_channels, boc[0], 0, false);
+    {  // conv_in on the MFMA conv path: input channels zero-padded to 64 (one K step per filter tap)
+      conv_in.Cin = 64;
+      conv_in.Cout = boc[0];
+      conv_in.b = Wd("conv_in.bias");
+      check_shape("conv_in.weight", {boc[0], cfg.in_channels, 3, 3});
+      void* wp = pack_alloc((size_t)boc[0] * 9 * 64 * esz());
+      pack_conv_into(Wd("conv_in.weight"), wp, boc[0], cfg.in_channels, 0, 64);
+      conv_in.Wp = wp;
+    }
     time1 = make_lin("time_embedding.linear_1", boc[0], ted, true, false);
     time2 = make_lin("time_embedding.linear_2", ted, ted, true, false);
     if (cfg.addition_embed) {
@@ -576,11 +627,13 @@ struct smi_engine {
     }
     norm_out = make_norm("conv_norm_out", boc[0], 1e-5f);
     conv_out = make_conv("conv_out", boc[0], cfg.out_channels, 0, false);
-    {  // conv_out gradient filter for the direct small-channel kernel: [C0][9*out_channels], flipped taps
-      void* wg = pack_alloc((size_t)boc[0] * cfg.out_channels * 9 * esz());
-      pack_conv_into(Wd("conv_out.weight"), wg, cfg.out_channels, boc[0], 2);
+    {  // conv_out gradient filter [C0][9*64]: flipped taps, d_eps channels zero-padded to 64 (MFMA conv path)
+      void* wg = pack_alloc((size_t)boc[0] * 9 * 64 * esz());
+      pack_conv_into(Wd("conv_out.weight"), wg, cfg.out_channels, boc[0], 2, 64);
       conv_out.Wg = wg;
     }
+    build_kv_group();
+    finish_lora();
     gscale = (float*)pack_alloc(260 * sizeof(float));
     for (size_t i = 0; i < sites.size(); ++i)
       if (!site_used[i] && !err) {
@@ -588,6 +641,37 @@ struct smi_engine {
                   site_names[i].c_str());
         err = true;
       }
+  }
+
+  // every cross-attention k|v projection reads the same ctx: stack them into ONE GEMM per pass (70 launches of a
+  // 3x10-tile grid -> one launch of a 3x1300-tile grid on SD-XL).  Only when no LoRA adapts to_k / to_v.
+  template <typename F>
+  void for_each_tblock(F f) {
+    for (auto& lv : down) for (auto& t : lv.att) for (auto& tb : t.blocks) f(tb);
+    for (auto& t : mid.att) for (auto& tb : t.blocks) f(tb);
+    for (auto& lv : up) for (auto& t : lv.att) for (auto& tb : t.blocks) f(tb);
+  }
+  void build_kv_group() {
+    int64_t total = 0;
+    bool any_lora = false;
+    for_each_tblock([&](TBlock& tb) {
+      tb.kv_col = total;
+      total += tb.kv2.out;
+      any_lora |= tb.kv2.nsite > 0;
+    });
+    kv_grouped = !any_lora && total > 0 && total * (int64_t)cfg.cross_attention_dim * 2 < 0xFFFFFFF0ll;
+    if (!kv_grouped) return;
+    const int D = cfg.cross_attention_dim;
+    char* w = (char*)pack_alloc((size_t)total * D * esz());
+    for_each_tblock([&](TBlock& tb) {
+      if (!dry && !err && tb.kv2.W)
+        (void)hipMemcpyAsync(w + (size_t)tb.kv_col * D * esz(), tb.kv2.W, (size_t)tb.kv2.out * D * esz(),
+                             hipMemcpyDeviceToDevice, stream);
+    });
+    kv_all.name = "grouped attn2.to_k|to_v";
+    kv_all.W = w;
+    kv_all.in = D;
+    kv_all.out = (int)total;
   }
 
   // ---------------------------------------------------------------------------------------------------------
@@ -601,10 +685,20 @@ struct smi_engine {
     const int rtot = L.rank * L.nseg;
     float* xa = nullptr;
     const float lscale = mult * L.scale;
-    if (lon) {
-      xa = alloc_f32((size_t)x->rows * rtot);
-      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_down(dtype, x->p, x->cols, lora_down + L.off_down, L.in, 1, xa, rtot, (int)x->rows, L.in, rtot,
-                           stream));
+    if (lon) {  // xa[M, rows_pad] = x * down^T as one MFMA GEMM on the 16-bit shadow copy (fp32 result)
+      xa = alloc_f32((size_t)x->rows * L.rows_pad);
+      GemmParams g;
+      g.dtype = dtype;
+      g.A = x->p;
+      g.lda = x->cols;
+      g.W = shadow_ptr(L.sh_down);
+      g.C = xa;
+      g.ldc = L.rows_pad;
+      g.out_f32 = 1;
+      g.M = (int)x->rows;
+      g.N = L.rows_pad;
+      g.K = L.in;
+      RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0, launch_gemm(g, stream));
     }
     GemmParams p;
     p.dtype = dtype;
@@ -623,7 +717,7 @@ struct smi_engine {
     }
     if (lon) {
       p.lora_xa = xa;
-      p.ld_xa = rtot;
+      p.ld_xa = L.rows_pad;
       p.lora_up = lora_up + L.off_up;
       p.up_sn = L.rank;
       p.up_sq = 1;
@@ -650,20 +744,32 @@ struct smi_engine {
     if (lon) {
       const int cs = L->out / L->nseg;
       const int r = L->rank;
-      dxa = alloc_f32((size_t)M * rtot);
+      const int rp = L->rows_pad;
+      dxa = alloc_f32((size_t)M * rp);
       float* scratch = alloc_f32(std::max(lora_wgrad_scratch_floats(M, cs, r), lora_wgrad_scratch_floats(M, L->in, r)));
+      {  // dxa[M, rows_pad] = dy * upT^T : one MFMA GEMM against the block-diagonal 16-bit shadow of lora_up
+        GemmParams g;
+        g.dtype = dtype;
+        g.A = dy;
+        g.lda = L->out;
+        g.W = shadow_ptr(L->sh_up);
+        g.C = dxa;
+        g.ldc = rp;
+        g.out_f32 = 1;
+        g.M = M;
+        g.N = rp;
+        g.K = L->out;
+        RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0, launch_gemm(g, stream));
+      }
       for (int s = 0; s < L->nseg; ++s) {
         const char* dys = (const char*)dy + (size_t)s * cs * esz();
         // d(up_s)[n][q] += lscale/S * sum_m dy[m][s*cs+n] * xa[m][s*r+q]
-        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, xa + s * r, rtot, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
+        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, xa + s * r, rp, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
                               cs, r, lscale, gscale + 1, scratch, stream));
-        // dxa_s[m][q] = sum_n dy[m][s*cs+n] * up_s[n][q]
-        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_down(dtype, dys, L->out, bw_up + L->off_up + (int64_t)s * cs * r, 1, r, dxa + s * r, rtot,
-                             M, cs, r, stream));
       }
       for (int s = 0; s < L->nseg; ++s) {
         // d(down_s)[q][k] += lscale/S * sum_m dxa[m][s*r+q] * x[m][k]
-        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, rtot, x->p, x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
+        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, L->rows_pad, x->p, x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
                               L->in, 1, M, L->in, r, lscale, gscale + 1, scratch, stream));
       }
     }
@@ -691,7 +797,7 @@ struct smi_engine {
       }
       if (lon) {
         p.lora_xa = dxa;
-        p.ld_xa = rtot;
+        p.ld_xa = L->rows_pad;
         p.lora_up = bw_down + L->off_down;  // A_cat [rtot, in] read as [in][rtot]
         p.up_sn = 1;
         p.up_sq = L->in;
@@ -769,7 +875,8 @@ struct smi_engine {
   }
 
   // self-attention on a fused [M, 3C] q|k|v tensor, or cross-attention on q [M, C] and kv [n*L, 2C]
-  Ten* attention(Ten* qkv, Ten* q, Ten* kv, int heads, int C, int nbatch, int Nq, int Nk) {
+  Ten* attention(Ten* qkv, Ten* q, Ten* kv, int heads, int C, int nbatch, int Nq, int Nk,
+                 const void* kv_ext = nullptr, int64_t ld_ext = 0) {
     Ten* src_q = qkv ? qkv : q;
     Ten* o = new_ten(src_q->rows, C, src_q->n, src_q->H, src_q->W);
     float* lse = alloc_f32((size_t)nbatch * heads * Nq);
@@ -789,15 +896,15 @@ struct smi_engine {
     } else {
       p.Q = q->p;
       p.ldq = C;
-      p.K = kv->p;
-      p.V = (char*)kv->p + (size_t)C * esz();
-      p.ldk = p.ldv = 2 * C;
+      p.K = kv_ext ? kv_ext : kv->p;
+      p.V = (const char*)p.K + (size_t)C * esz();
+      p.ldk = p.ldv = kv_ext ? ld_ext : 2 * C;
     }
     p.O = o->p;
     p.ldo = C;
     p.lse = lse;
     RUNP(SMI_PROF_ATTN, 4.0 * nbatch * heads * (double)Nq * Nk * p.D, 0.0, launch_attn_fwd(p, stream));
-    o->ng = qkv ? qkv->ng : (q->ng || kv->ng);
+    o->ng = qkv ? qkv->ng : (q->ng || (kv && kv->ng));
     if (saving && o->ng) {
       tape.push_back([=]() {
         if (!o->g) return;
@@ -817,7 +924,7 @@ struct smi_engine {
             b.dQ = grad_slot(q, had);
             b.lddq = C;
           }
-          if (kv->ng) {
+          if (kv && kv->ng) {
             char* g = (char*)grad_slot(kv, had);
             b.dK = g;
             b.dV = g + (size_t)C * esz();
@@ -987,8 +1094,13 @@ struct smi_engine {
       h = linear(o, tb.out1, h);
       nrm = layernorm(h, tb.n2);
       Ten* q = linear(nrm, tb.q2);
-      Ten* kv = linear(ctx, tb.kv2);
-      o = attention(nullptr, q, kv, t.heads, C, nb, Nq, ctx_len);
+      if (kv_grouped) {
+        o = attention(nullptr, q, nullptr, t.heads, C, nb, Nq, ctx_len,
+                      (const char*)kv_all_out->p + (size_t)tb.kv_col * esz(), kv_all.out);
+      } else {
+        Ten* kv = linear(ctx, tb.kv2);
+        o = attention(nullptr, q, kv, t.heads, C, nb, Nq, ctx_len);
+      }
       h = linear(o, tb.out2, h);
       nrm = layernorm(h, tb.n3);
       Ten* pj = linear(nrm, tb.ff1);
@@ -1037,6 +1149,8 @@ struct smi_engine {
       emb = sum;
     }
     Ten* temb_act = silu(emb);
+    if (!prep_sites.empty() && (dry || (lora_down && lora_up && mult != 0.f)))
+      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_prep(dtype, prep_sites_dev, (int)prep_sites.size(), lora_down, lora_up, lora_shadow, stream));
 
     // ---- context as a [n*L, D] tensor (borrowed)
     tens->emplace_back();
@@ -1046,11 +1160,30 @@ struct smi_engine {
     ctx->cols = cfg.cross_attention_dim;
     ctx->n = n;
 
-    // ---- conv_in
-    Ten* x0 = new_ten((int64_t)n * HW, cfg.in_channels, n, H, Wd_);
-    RUN(launch_nchw_to_nhwc(dtype, sample, 1, x0->p, n, cfg.in_channels, HW, cfg.in_channels, 1.f, stream));
+    if (kv_grouped) kv_all_out = linear(ctx, kv_all);
+
+    // ---- conv_in (MFMA implicit GEMM on the 64-channel zero-padded latent)
+    Ten* x0 = new_ten((int64_t)n * HW, 64, n, H, Wd_);
+    RUN(launch_nchw_to_nhwc(dtype, sample, 1, x0->p, n, cfg.in_channels, HW, 64, 1.f, stream));
     Ten* h = new_ten((int64_t)n * HW, C0, n, H, Wd_);
-    RUNP(SMI_PROF_CONV, 0.0, 0.0, launch_conv3x3_small(dtype, x0->p, conv_in.Wp, conv_in.b, h->p, 0, n, H, Wd_, cfg.in_channels, C0, stream));
+    {
+      GemmParams p;
+      p.dtype = dtype;
+      p.conv = 1;
+      p.A = x0->p;
+      p.W = conv_in.Wp;
+      p.C = h->p;
+      p.ldc = C0;
+      p.M = (int)h->rows;
+      p.N = C0;
+      p.K = 9 * 64;
+      p.bias = conv_in.b;
+      p.Nb = n;
+      p.Hin = p.Hout = H;
+      p.Win = p.Wout = Wd_;
+      p.Cin = 64;
+      RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * 9 * cfg.in_channels, 0.0, launch_gemm(p, stream));
+    }
 
     std::vector<Ten*> skips;
     skips.push_back(h);
@@ -1110,7 +1243,21 @@ struct smi_engine {
         if (!y->g) return;
         bool had;
         void* dx = grad_slot(hn, had);
-        RUNP(SMI_PROF_CONV, 0.0, 0.0, launch_conv3x3_small(dtype, y->g, conv_out.Wg, nullptr, dx, 0, n, H, Wd_, cfg.out_channels, C0, stream));
+        GemmParams b;
+        b.dtype = dtype;
+        b.conv = 1;
+        b.A = y->g;  // [rows, 64]: d_eps channels zero-padded
+        b.W = conv_out.Wg;
+        b.C = dx;
+        b.ldc = C0;
+        b.M = (int)hn->rows;
+        b.N = C0;
+        b.K = 9 * 64;
+        b.Nb = n;
+        b.Hin = b.Hout = H;
+        b.Win = b.Wout = Wd_;
+        b.Cin = 64;
+        RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * 9 * cfg.out_channels, 0.0, launch_gemm(b, stream));
       });
     }
     if (save) {
@@ -1143,8 +1290,8 @@ struct smi_engine {
     if (!y->ng) return 0;  // adaptor off: nothing depends on the LoRA parameters
     const int64_t cnt = (int64_t)n * cfg.out_channels * HW;
     RUN(launch_grad_scale(d_eps, cnt, gscale, stream));
-    y->g = alloc_t(y->rows, cfg.out_channels);
-    RUN(launch_nchw_to_nhwc_scaled(dtype, d_eps, y->g, n, cfg.out_channels, HW, cfg.out_channels, gscale, stream));
+    y->g = alloc_t(y->rows, 64);
+    RUN(launch_nchw_to_nhwc_scaled(dtype, d_eps, y->g, n, cfg.out_channels, HW, 64, gscale, stream));
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();
     tape.clear();
     tape_valid = false;
@@ -1251,6 +1398,7 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
   e->arena[1].base = base + r[0] + r[1];
   e->arena[1].cap = r[2];
   e->build();
+  if (!e->err) (void)hipStreamSynchronize(e->stream);
   if (e->err || hipGetLastError() != hipSuccess) {
     if (!e->err) set_error("HIP error while packing weights");
     delete e;

@@ -128,6 +128,13 @@ int launch_lora_wgrad(int dtype, const float* P, int64_t ldp, const void* X, int
                       int64_t so_k, int M, int K, int r, float alpha, const float* alpha_dev, float* scratch,
                       hipStream_t stream);
 size_t lora_wgrad_scratch_floats(int M, int K, int r);
+// 16-bit shadow copies of the LoRA matrices as GEMM operands (see lora.hip); sites_dev: device array of HostLoraPrepSite
+struct HostLoraPrepSite {
+  int64_t off_down, off_up, dst_down, dst_up;
+  int r, nseg, K, cs, rows_pad;
+};
+int launch_lora_prep(int dtype, const void* sites_dev, int n_sites, const float* down, const float* up, void* shadow,
+                     hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // slider-step elementwise ops (K9-K11)

@@ -116,25 +116,63 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(const float* __
 }
 
 // dW[q*so_r + k*so_k] += alpha * alpha_dev * sum_s partial[s][q][k]   (fixed summation order: deterministic)
-// one thread per output element; the nsplit partials of consecutive k are consecutive in memory -> coalesced
-__global__ void lora_wgrad_final_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ dW,
-                                        int64_t so_r, int64_t so_k, int K, int r, float alpha,
-                                        const float* __restrict__ alpha_dev) {
+// block = 32 consecutive outputs x 8 split-groups; group g sums splits g, g+8, ...; LDS combines the 8 groups.
+__global__ __launch_bounds__(256) void lora_wgrad_final_kernel(const float* __restrict__ partial, int nsplit,
+                                                               float* __restrict__ dW, int64_t so_r, int64_t so_k,
+                                                               int K, int r, float alpha,
+                                                               const float* __restrict__ alpha_dev) {
+  __shared__ float red[8][33];
   const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
   const int64_t total = (int64_t)r * K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  float s = 0.f;
+  if (i < total) {
+    for (int sp = g; sp < nsplit; sp += 8) s += partial[(int64_t)sp * total + i];
+  }
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][e];
     const int q = (int)(i / K);
     const int k = (int)(i - (int64_t)q * K);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int sp = 0;
-    for (; sp + 3 < nsplit; sp += 4) {
-      s0 += partial[((int64_t)(sp + 0) * r + q) * K + k];
-      s1 += partial[((int64_t)(sp + 1) * r + q) * K + k];
-      s2 += partial[((int64_t)(sp + 2) * r + q) * K + k];
-      s3 += partial[((int64_t)(sp + 3) * r + q) * K + k];
+    dW[q * so_r + k * so_k] += a * t;
+  }
+}
+
+// fp32 flat LoRA parameters -> 16-bit GEMM operands, once per forward, for every adapted (possibly fused) GEMM:
+//   downT[rows_pad, K]        = lora_down rows of the site (zero rows up to rows_pad)
+//   upT  [rows_pad, nseg*cs]  block-diagonal: upT[s*r + q][s*cs + n] = lora_up_s[n][q]
+struct LoraPrepSite {
+  int64_t off_down, off_up;  // into the flat fp32 buffers
+  int64_t dst_down, dst_up;  // element offsets into the 16-bit shadow buffer
+  int r, nseg, K, cs, rows_pad;
+};
+template <typename T>
+__global__ void lora_prep_kernel(const LoraPrepSite* __restrict__ sites, const float* __restrict__ down,
+                                 const float* __restrict__ up, T* __restrict__ shadow) {
+  const LoraPrepSite st = sites[blockIdx.y];
+  const int rtot = st.r * st.nseg;
+  const int64_t n_down = (int64_t)st.rows_pad * st.K;
+  const int64_t n_up = (int64_t)st.rows_pad * st.nseg * st.cs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_down + n_up;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n_down) {
+      const int row = (int)(i / st.K);
+      shadow[st.dst_down + i] = from_f<T>(row < rtot ? down[st.off_down + i] : 0.f);
+    } else {
+      const int64_t j = i - n_down;
+      const int ncols = st.nseg * st.cs;
+      const int row = (int)(j / ncols), col = (int)(j - (int64_t)row * ncols);
+      float v = 0.f;
+      if (row < rtot) {
+        const int sgm = row / st.r, q = row - sgm * st.r;
+        if (col / st.cs == sgm) v = up[st.off_up + ((int64_t)sgm * st.cs + (col - sgm * st.cs)) * st.r + q];
+      }
+      shadow[st.dst_up + j] = from_f<T>(v);
     }
-    for (; sp < nsplit; ++sp) s0 += partial[((int64_t)sp * r + q) * K + k];
-    dW[q * so_r + k * so_k] += a * ((s0 + s1) + (s2 + s3));
   }
 }
 
@@ -166,7 +204,7 @@ int wgrad_t(const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, 
   else L(32);
 #undef L
   const int64_t total = (int64_t)r * K;
-  hipLaunchKernelGGL(lora_wgrad_final_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, scratch, nsplit, dW,
+  hipLaunchKernelGGL(lora_wgrad_final_kernel, dim3((int)((total + 31) / 32)), dim3(256), 0, st, scratch, nsplit, dW,
                      so_r, so_k, K, r, alpha, alpha_dev);
   SMI_HIP(hipGetLastError());
   return 0;
@@ -190,6 +228,18 @@ int launch_lora_wgrad(int dtype, const float* P, int64_t ldp, const void* X, int
   SMI_CHECK(r >= 1 && r <= 32 && K % 8 == 0 && ldx % 8 == 0, "lora_wgrad: r=%d K=%d", r, K);
   return dtype == DT_F16 ? wgrad_t<f16>(P, ldp, X, ldx, dW, so_r, so_k, M, K, r, alpha, alpha_dev, scratch, stream)
                          : wgrad_t<bf16>(P, ldp, X, ldx, dW, so_r, so_k, M, K, r, alpha, alpha_dev, scratch, stream);
+}
+
+int launch_lora_prep(int dtype, const void* sites_dev, int n_sites, const float* down, const float* up, void* shadow,
+                     hipStream_t stream) {
+  if (n_sites <= 0) return 0;
+  dim3 grid(16, n_sites);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(lora_prep_kernel<f16>, grid, dim3(256), 0, stream, (const LoraPrepSite*)sites_dev, down, up, (f16*)shadow);
+  else
+    hipLaunchKernelGGL(lora_prep_kernel<bf16>, grid, dim3(256), 0, stream, (const LoraPrepSite*)sites_dev, down, up, (bf16*)shadow);
+  SMI_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace smi

@@ -11,7 +11,7 @@
 namespace smi {
 namespace {
 
-constexpr int GN_ROWS_PER_CHUNK = 256;
+constexpr int GN_ROWS_PER_CHUNK = 64;  // small chunks: >= 1024 workgroups on the large feature maps
 
 struct GnGeom {
   int cols8;  // C / 8
@@ -63,27 +63,37 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
       }
     }
     if (cok) {
-      for (int r = row0 + rsub; r < row1; r += gg.rpar) {
-        const int64_t off = ((int64_t)n * HW + r) * C + col * 8;
-        Pack8<T> xv;
-        xv.u = *reinterpret_cast<const u32x4*>(x + off);
-        if (MODE == 0) {
+      // 4 independent row loads in flight per thread (otherwise a chain of dependent HBM latencies)
+      for (int r0 = row0 + rsub; r0 < row1; r0 += 4 * gg.rpar) {
+        Pack8<T> xv4[4], dv4[4];
+        bool ok4[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = to_f(xv.e[e]);
-            s0[e] += v;
-            s1[e] += v * v;
-          }
-        } else {
-          Pack8<T> dv;
-          dv.u = *reinterpret_cast<const u32x4*>(dy + off);
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * gg.rpar;
+          ok4[u] = r < row1;
+          const int64_t off = ((int64_t)n * HW + (ok4[u] ? r : row0)) * C + col * 8;
+          xv4[u].u = *reinterpret_cast<const u32x4*>(x + off);
+          if (MODE == 1) dv4[u].u = *reinterpret_cast<const u32x4*>(dy + off);
+        }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float z = to_f(xv.e[e]) * av[e] + bv[e];
-            float dz = to_f(dv.e[e]);
-            if (SILU) dz *= dsilu_f(z);
-            s0[e] += dz * gv[e];
-            s1[e] += dz * (z - be[e]);
+        for (int u = 0; u < 4; ++u) {
+          if (!ok4[u]) continue;
+          if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = to_f(xv4[u].e[e]);
+              s0[e] += v;
+              s1[e] += v * v;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float z = to_f(xv4[u].e[e]) * av[e] + bv[e];
+              float dz = to_f(dv4[u].e[e]);
+              if (SILU) dz *= dsilu_f(z);
+              s0[e] += dz * gv[e];
+              s1[e] += dz * (z - be[e]);
+            }
           }
         }
       }

@@ -183,7 +183,7 @@ def test_groupnorm_forward_backward(lib, dt, nb, HW, Cc, G, silu):
     gamma, beta = (1 + 0.1 * rnd(Cc, dt=dt, seed=2)).to(dt), rnd(Cc, dt=dt, scale=0.1, seed=3)
     dy = rnd(nb, HW, Cc, dt=dt, seed=4)
     y, dx = torch.empty_like(x), torch.empty_like(x)
-    nchunk = (HW + 255) // 256
+    nchunk = (HW + 63) // 64
     scratch = torch.empty(2 * nb * Cc + nb * G * 2 + nb * nchunk * G * 2 + 2 * nb * Cc + 64, device="cuda")
     chk(lib, lib.smi_op_groupnorm(dcode(dt), P(x), P(gamma), P(beta), P(y), P(dy), P(dx), P(scratch), nb, HW, Cc, G,
                                   1e-5, silu, None))
