@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--skip-dead-cfg-half", action="store_true",
                     help="drop the algebraically dead unconditional half (CFG scale 1); reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-passes", action="store_true",
+                    help="run the four guidance passes as four UNet calls instead of one batched pass")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,7 +206,7 @@ def main():
         pooled = {k: torch.randn(1, pdim, generator=g) for k in keys}
         time_ids = torch.tensor([[float(res), float(res), 0.0, 0.0, float(res), float(res)]])
     step = SliderStep(unet, net, sched, lr=lr, weight_decay=wd, max_grad_norm=max_norm, cfg_scale=1.0,
-                      skip_dead_cfg_half=args.skip_dead_cfg_half)
+                      skip_dead_cfg_half=args.skip_dead_cfg_half, batch_passes=not args.separate_passes)
     cond = step.make_conditioning(emb, B, pooled, time_ids)
     lat = res // 8
     denoised = torch.randn(B, 4, lat, lat, generator=torch.Generator().manual_seed(3 + rank)).cuda()
@@ -260,7 +262,9 @@ def main():
                        "unet_batch": B if args.skip_dead_cfg_half else 2 * B, "global_batch": B * world,
                        "lora_rank": lrank, "train_method": "noxattn", "lora_params": int(net.flat.numel()),
                        "scheduler": sched_name, "parallelism": f"dp{world}", "pre_roll": "excluded",
-                       "skip_dead_cfg_half": bool(args.skip_dead_cfg_half)},
+                       "skip_dead_cfg_half": bool(args.skip_dead_cfg_half),
+                       "guidance_passes": "4 separate UNet calls" if args.separate_passes else
+                       "1 batched UNet call (3 frozen + 1 adapted sub-batches)"},
             "samples_per_s": args.steps * B * world / elapsed,
             "loss": loss_val,
             "step_algorithmic_tflop": step_flops / 1e12,

@@ -76,17 +76,19 @@ typedef struct smi_engine smi_engine;
 const char* smi_last_error(void);
 
 /* Bytes of device workspace an engine needs for UNet batch `batch` (= 2B of the reference's CFG-doubled batch,
- * train_util.py:285), latent h x w, context length ctx_len, and the given set of adapted layers. */
-int smi_workspace_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int h, int w,
-                        int ctx_len, size_t* bytes);
+ * train_util.py:285, or 4 x 2B when the four guidance passes run as one batched pass), of which at most
+ * `batch_adapted` samples are LoRA-adapted and differentiated, latent h x w, context length ctx_len, and the given
+ * set of adapted layers. */
+int smi_workspace_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch,
+                        int batch_adapted, int h, int w, int ctx_len, size_t* bytes);
 
 /* Builds the engine: packs the frozen weights into MFMA-friendly layouts inside `workspace` (transposed copies for
  * the activation-gradient GEMMs, (ky,kx,ci)-ordered conv filters, fused q|k|v) and lays out the activation arenas.
  * Replaces: unet.to(device, dtype); unet.requires_grad_(False); unet.eval(); LoRANetwork(...).apply_to()
  * (train_lora.py:67-78). */
 int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weights, const smi_lora_site* sites,
-               int n_sites, int batch, int h, int w, int ctx_len, void* workspace, size_t workspace_bytes,
-               void* stream, smi_engine** out);
+               int n_sites, int batch, int batch_adapted, int h, int w, int ctx_len, void* workspace,
+               size_t workspace_bytes, void* stream, smi_engine** out);
 void smi_destroy(smi_engine* e);
 
 /* eps = unet(sample, t, ctx[, text_embeds, time_ids]).sample           (train_util.py:290-294, 471-476)
@@ -101,6 +103,16 @@ void smi_destroy(smi_engine* e);
 int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, const void* ctx,
                      const void* text_embeds, const float* time_ids, const float* lora_down_flat,
                      const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out);
+
+/* The four guidance passes of one slider step as ONE UNet pass: samples are independent through the network, so the
+ * positive / neutral / negative batches (adaptor off) and the target batch (adaptor on) are stacked into a batch of
+ * n = 4 x 2B with the `n_adapted` = 2B target samples LAST.  Only those samples receive the LoRA delta and only their
+ * activations are differentiated by smi_unet_backward (whose d_eps then has n_adapted samples).  Same arithmetic per
+ * sample as four smi_unet_forward calls; 4x larger GEMM M, ~60 % fewer launches.  n_adapted == n gives
+ * smi_unet_forward. */
+int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* sample, float timestep, const void* ctx,
+                             const void* text_embeds, const float* time_ids, const float* lora_down_flat,
+                             const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out);
 
 /* Backward of the last save_for_backward forward: accumulates (+=) d(loss)/d(lora_down), d(loss)/d(lora_up) into
  * the flat fp32 gradient buffers (same offsets as the parameters).  Activation gradients are propagated only as far

@@ -45,10 +45,12 @@ _lib = None
 _SIGS = {
     "smi_last_error": (C.c_char_p, []),
     "smi_workspace_bytes": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(LoraSiteC), C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.POINTER(C.c_size_t)]),
+                                      C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "smi_create": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(WeightC), C.c_int, C.POINTER(LoraSiteC), C.c_int,
-                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                              C.POINTER(C.c_void_p)]),
+    "smi_unet_forward_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "smi_destroy": (None, [C.c_void_p]),
     "smi_unet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
@@ -152,10 +154,12 @@ def make_sites(sites: Sequence[dict]):
     return arr, keep
 
 
-def workspace_bytes(cfg_c: UNetConfigC, sites: Sequence[dict], batch: int, h: int, w: int, ctx_len: int) -> int:
+def workspace_bytes(cfg_c: UNetConfigC, sites: Sequence[dict], batch: int, h: int, w: int, ctx_len: int,
+                    batch_adapted: Optional[int] = None) -> int:
     arr, _keep = make_sites(sites)
     out = C.c_size_t(0)
-    check(lib().smi_workspace_bytes(C.byref(cfg_c), arr, len(sites), batch, h, w, ctx_len, C.byref(out)),
+    ba = batch if batch_adapted is None else batch_adapted
+    check(lib().smi_workspace_bytes(C.byref(cfg_c), arr, len(sites), batch, ba, h, w, ctx_len, C.byref(out)),
           "smi_workspace_bytes")
     return out.value
 
@@ -164,12 +168,13 @@ class Engine:
     """Owns one smi_engine plus the torch tensors backing its workspace."""
 
     def __init__(self, cfg, dtype: torch.dtype, state: dict, sites: Sequence[dict], batch: int, h: int, w: int,
-                 ctx_len: int, device):
+                 ctx_len: int, device, batch_adapted: Optional[int] = None):
         self.cfg_c = make_config(cfg, dtype)
         self.dtype = dtype
         self.batch, self.h, self.w, self.ctx_len = batch, h, w, ctx_len
+        self.batch_adapted = batch if batch_adapted is None else batch_adapted
         self.sites = list(sites)
-        nbytes = workspace_bytes(self.cfg_c, sites, batch, h, w, ctx_len)
+        nbytes = workspace_bytes(self.cfg_c, sites, batch, h, w, ctx_len, self.batch_adapted)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self._weights_keepalive = []
         warr = (WeightC * len(state))()
@@ -188,18 +193,21 @@ class Engine:
         sarr, keep = make_sites(sites)
         handle = C.c_void_p()
         with torch.cuda.device(self.workspace.device):
-            check(lib().smi_create(C.byref(self.cfg_c), warr, len(state), sarr, len(sites), batch, h, w, ctx_len,
-                                   ptr(self.workspace), nbytes, stream_ptr(), C.byref(handle)), "smi_create")
+            check(lib().smi_create(C.byref(self.cfg_c), warr, len(state), sarr, len(sites), batch, self.batch_adapted,
+                                   h, w, ctx_len, ptr(self.workspace), nbytes, stream_ptr(), C.byref(handle)),
+                  "smi_create")
         self.handle = handle
         self.stream = torch.cuda.current_stream().cuda_stream
 
     def forward(self, sample: torch.Tensor, timestep: float, ctx: torch.Tensor, text_embeds, time_ids, lora_down,
-                lora_up, multiplier: float, save: bool) -> torch.Tensor:
+                lora_up, multiplier: float, save: bool, n_adapted: Optional[int] = None) -> torch.Tensor:
+        """n_adapted: the LAST n_adapted samples get the LoRA delta and are differentiated (default: all)."""
         n = sample.shape[0]
+        na = min(n, self.batch_adapted) if n_adapted is None else n_adapted
         eps = torch.empty(sample.shape, dtype=torch.float32, device=sample.device)
-        check(lib().smi_unet_forward(self.handle, n, ptr(sample), float(timestep), ptr(ctx), ptr(text_embeds),
-                                     ptr(time_ids), ptr(lora_down), ptr(lora_up), float(multiplier), int(save),
-                                     ptr(eps)), "smi_unet_forward")
+        check(lib().smi_unet_forward_batched(self.handle, n, na, ptr(sample), float(timestep), ptr(ctx),
+                                             ptr(text_embeds), ptr(time_ids), ptr(lora_down), ptr(lora_up),
+                                             float(multiplier), int(save), ptr(eps)), "smi_unet_forward_batched")
         return eps
 
     def backward(self, d_eps: torch.Tensor, d_down: torch.Tensor, d_up: torch.Tensor):

@@ -112,6 +112,9 @@ struct Ten {
   int64_t rows = 0;
   int cols = 0;
   int n = 0, H = 0, W = 0;  // rows = n*H*W for image tensors
+  // first row of the ADAPTED samples: a batched pass carries frozen samples first and the adapted (LoRA on,
+  // differentiated) samples last; gradients `g` cover rows [arow0, rows) only
+  int64_t arow0 = 0;
   bool ng = false;
 };
 
@@ -228,7 +231,9 @@ struct smi_engine {
   float* d_down = nullptr;
   float* d_up = nullptr;
   Ten* out_ten = nullptr;  // conv_out result (f32 [rows, 4])
-  int last_n = 0;
+  int n_ad = 0;     // adapted samples of the pass in flight (the last n_ad of n)
+  int bw_n_ad = 0;  // ... of the saved pass
+  int max_n_ad = 0;
 
   size_t esz() const { return 2; }
 
@@ -315,9 +320,12 @@ struct smi_engine {
     t->n = n;
     t->H = H;
     t->W = W;
+    t->arow0 = n > 0 ? (int64_t)(n - n_ad) * (rows / n) : 0;
     t->p = arena_alloc((size_t)rows * cols * (elt ? elt : esz()));
     return t;
   }
+  int64_t MA(const Ten* t) const { return t->rows - t->arow0; }  // adapted rows
+  char* PA(const Ten* t) const { return (char*)t->p + (size_t)t->arow0 * t->cols * esz(); }
   void* arena_alloc(size_t bytes) {
     void* p = cur->alloc(bytes);
     if (!dry && cur->overflow && !err) {  // never launch a kernel on memory we do not own
@@ -332,14 +340,14 @@ struct smi_engine {
   // gradient slot of t: returns buffer to write; `had` tells whether a gradient is already accumulated there
   void* grad_slot(Ten* t, bool& had) {
     had = t->g != nullptr;
-    if (!had) t->g = alloc_t(t->rows, t->cols);
+    if (!had) t->g = alloc_t(MA(t), t->cols);
     return t->g;
   }
   void accumulate(Ten* t, void* g) {
     if (!t->g) {
       t->g = g;  // alias: g is dead after its producer's closure
     } else {
-      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, t->g, g, t->g, t->rows * t->cols, stream));
+      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, t->g, g, t->g, MA(t) * t->cols, stream));
     }
   }
 
@@ -686,16 +694,16 @@ struct smi_engine {
     float* xa = nullptr;
     const float lscale = mult * L.scale;
     if (lon) {  // xa[M, rows_pad] = x * down^T as one MFMA GEMM on the 16-bit shadow copy (fp32 result)
-      xa = alloc_f32((size_t)x->rows * L.rows_pad);
+      xa = alloc_f32((size_t)MA(x) * L.rows_pad);
       GemmParams g;
       g.dtype = dtype;
-      g.A = x->p;
+      g.A = PA(x);
       g.lda = x->cols;
       g.W = shadow_ptr(L.sh_down);
       g.C = xa;
       g.ldc = L.rows_pad;
       g.out_f32 = 1;
-      g.M = (int)x->rows;
+      g.M = (int)MA(x);
       g.N = L.rows_pad;
       g.K = L.in;
       RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0, launch_gemm(g, stream));
@@ -724,9 +732,11 @@ struct smi_engine {
       p.lora_r = L.rank;
       p.lora_seg = L.nseg > 1 ? L.out / L.nseg : 0;
       p.lora_scale = lscale;
+      p.lora_row0 = (int)x->arow0;
     }
     RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
          launch_gemm(p, stream));
+    y->arow0 = x->arow0;
     y->ng = lon || x->ng || (res && res->ng);
     if (saving && y->ng) {
       const Lin* Lp = &L;
@@ -738,7 +748,7 @@ struct smi_engine {
     void* dy = y->g;
     if (!dy) return;
     if (res && res->ng) accumulate(res, dy);
-    const int M = (int)x->rows;
+    const int M = (int)MA(x);
     const int rtot = L->rank * L->nseg;
     float* dxa = nullptr;
     if (lon) {
@@ -769,7 +779,7 @@ struct smi_engine {
       }
       for (int s = 0; s < L->nseg; ++s) {
         // d(down_s)[q][k] += lscale/S * sum_m dxa[m][s*r+q] * x[m][k]
-        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, L->rows_pad, x->p, x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
+        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, L->rows_pad, PA(x), x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
                               L->in, 1, M, L->in, r, lscale, gscale + 1, scratch, stream));
       }
     }
@@ -821,7 +831,7 @@ struct smi_engine {
         if (!y->g) return;
         bool had;
         void* dx = grad_slot(x, had);
-        RUNP(SMI_PROF_NORM, 0.0, 6.0 * x->rows * x->cols, launch_layernorm_bwd(dtype, x->p, y->g, np->gamma, st, had ? dx : nullptr, dx, (int)x->rows, x->cols,
+        RUNP(SMI_PROF_NORM, 0.0, 6.0 * MA(x) * x->cols, launch_layernorm_bwd(dtype, PA(x), y->g, np->gamma, st + x->arow0 * 2, had ? dx : nullptr, dx, (int)MA(x), x->cols,
                                  stream));
       });
     }
@@ -845,7 +855,8 @@ struct smi_engine {
         bool had;
         void* dx = grad_slot(x, had);
         float* scr = alloc_f32(npart + (size_t)2 * x->n * C);
-        RUNP(SMI_PROF_NORM, 0.0, 6.0 * x->rows * x->cols, launch_groupnorm_bwd(dtype, x->p, y->g, np->gamma, np->beta, ab, mr, had ? dx : nullptr, dx, scr, x->n, HW,
+        const int n0 = (int)(x->arow0 / HW);  // first adapted sample
+        RUNP(SMI_PROF_NORM, 0.0, 6.0 * MA(x) * x->cols, launch_groupnorm_bwd(dtype, PA(x), y->g, np->gamma, np->beta, ab + (size_t)n0 * C, ab + (size_t)(x->n + n0) * C, mr + (size_t)n0 * G * 2, had ? dx : nullptr, dx, scr, x->n - n0, HW,
                                  C, G, silu ? 1 : 0, stream));
       });
     }
@@ -863,11 +874,11 @@ struct smi_engine {
         bool had;
         void* dp = grad_slot(pj, had);
         if (had) {  // never happens in this graph (proj has a single consumer); kept for safety
-          void* tmp = alloc_t(pj->rows, pj->cols);
-          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * pj->rows * C4, launch_geglu_bwd(dtype, pj->p, y->g, tmp, (int)pj->rows, C4, stream));
-          RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dp, tmp, dp, pj->rows * pj->cols, stream));
+          void* tmp = alloc_t(MA(pj), pj->cols);
+          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * MA(pj) * C4, launch_geglu_bwd(dtype, PA(pj), y->g, tmp, (int)MA(pj), C4, stream));
+          RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dp, tmp, dp, MA(pj) * pj->cols, stream));
         } else {
-          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * pj->rows * C4, launch_geglu_bwd(dtype, pj->p, y->g, dp, (int)pj->rows, C4, stream));
+          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * MA(pj) * C4, launch_geglu_bwd(dtype, PA(pj), y->g, dp, (int)MA(pj), C4, stream));
         }
       });
     }
@@ -909,9 +920,16 @@ struct smi_engine {
       tape.push_back([=]() {
         if (!o->g) return;
         AttnParams b = p;
+        const int b0 = (int)(o->arow0 / Nq);  // first adapted sample
+        b.B = nbatch - b0;
+        b.Q = (const char*)p.Q + (size_t)b0 * Nq * p.ldq * esz();
+        b.K = (const char*)p.K + (size_t)b0 * Nk * p.ldk * esz();
+        b.V = (const char*)p.V + (size_t)b0 * Nk * p.ldv * esz();
+        b.O = PA(o);
+        b.lse = p.lse + (size_t)b0 * heads * Nq;
         b.dO = o->g;
         b.lddo = C;
-        b.delta = alloc_f32((size_t)nbatch * heads * Nq);
+        b.delta = alloc_f32((size_t)b.B * heads * Nq);
         bool had;
         if (qkv) {
           char* g = (char*)grad_slot(qkv, had);
@@ -931,7 +949,7 @@ struct smi_engine {
             b.lddk = b.lddv = 2 * C;
           }
         }
-        RUNP(SMI_PROF_ATTN, 10.0 * nbatch * heads * (double)Nq * Nk * b.D, 0.0, launch_attn_bwd(b, stream));
+        RUNP(SMI_PROF_ATTN, 10.0 * b.B * heads * (double)Nq * Nk * b.D, 0.0, launch_attn_bwd(b, stream));
       });
     }
     return o;
@@ -990,12 +1008,12 @@ struct smi_engine {
         b.N = cp->Cin;
         b.K = 9 * cp->Cout;
         b.Cin = cp->Cout;
-        b.Nb = x->n;
+        b.Nb = x->n - (int)(x->arow0 / (Hin * Win));
         b.ldc = cp->Cin;
         if (cp->mode == 0) {
           b.Hin = b.Hout = Hin;
           b.Win = b.Wout = Win;
-          b.M = (int)x->rows;
+          b.M = (int)MA(x);
           b.C = dx;
           if (had) {
             b.res = dx;
@@ -1009,7 +1027,7 @@ struct smi_engine {
           b.Wout = Win;
           b.stride = 2;
           b.transposed = 1;
-          b.M = (int)x->rows;
+          b.M = (int)MA(x);
           b.C = dx;
           if (had) {
             b.res = dx;
@@ -1017,18 +1035,18 @@ struct smi_engine {
           }
           RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
         } else {  // upsample + conv: gradient on the 2x grid, then 2x2 sum-pool
-          void* du = alloc_t(y->rows, cp->Cin);
+          void* du = alloc_t(MA(y), cp->Cin);
           b.Hin = b.Hout = Hout;
           b.Win = b.Wout = Wout;
-          b.M = (int)y->rows;
+          b.M = (int)MA(y);
           b.C = du;
           RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
           if (had) {
-            void* tmp = alloc_t(x->rows, cp->Cin);
-            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, tmp, x->n, Hin, Win, cp->Cin, stream));
-            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dx, tmp, dx, x->rows * x->cols, stream));
+            void* tmp = alloc_t(MA(x), cp->Cin);
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, tmp, b.Nb, Hin, Win, cp->Cin, stream));
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dx, tmp, dx, MA(x) * x->cols, stream));
           } else {
-            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, dx, x->n, Hin, Win, cp->Cin, stream));
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, dx, b.Nb, Hin, Win, cp->Cin, stream));
           }
         }
       });
@@ -1052,12 +1070,12 @@ struct smi_engine {
             bool had;
             void* dst = grad_slot(t, had);
             if (had) {
-              void* tmp = alloc_t(t->rows, t->cols);
-              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, tmp, t->cols, 0, (int)t->rows,
+              void* tmp = alloc_t(MA(t), t->cols);
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, tmp, t->cols, 0, (int)MA(t),
                                    t->cols, stream));
-              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dst, tmp, dst, t->rows * t->cols, stream));
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dst, tmp, dst, MA(t) * t->cols, stream));
             } else {
-              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, dst, t->cols, 0, (int)t->rows,
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, dst, t->cols, 0, (int)MA(t),
                                    t->cols, stream));
             }
           }
@@ -1113,8 +1131,9 @@ struct smi_engine {
   // ---------------------------------------------------------------------------------------------------------
   // whole passes
   // ---------------------------------------------------------------------------------------------------------
-  int forward(int n, const float* sample, float timestep, const void* ctxp, const void* text_embeds,
+  int forward(int n, int n_adapted, const float* sample, float timestep, const void* ctxp, const void* text_embeds,
               const float* time_ids, bool save, float* eps_out) {
+    n_ad = n_adapted;
     cur = &arena[save ? 1 : 0];
     cur->reset();
     if (save) {
@@ -1159,6 +1178,7 @@ struct smi_engine {
     ctx->rows = (int64_t)n * ctx_len;
     ctx->cols = cfg.cross_attention_dim;
     ctx->n = n;
+    ctx->arow0 = (int64_t)(n - n_ad) * ctx_len;
 
     if (kv_grouped) kv_all_out = linear(ctx, kv_all);
 
@@ -1246,14 +1266,14 @@ struct smi_engine {
         GemmParams b;
         b.dtype = dtype;
         b.conv = 1;
-        b.A = y->g;  // [rows, 64]: d_eps channels zero-padded
+        b.A = y->g;  // [adapted rows, 64]: d_eps channels zero-padded
         b.W = conv_out.Wg;
         b.C = dx;
         b.ldc = C0;
-        b.M = (int)hn->rows;
+        b.M = (int)MA(hn);
         b.N = C0;
         b.K = 9 * 64;
-        b.Nb = n;
+        b.Nb = n_adapted;
         b.Hin = b.Hout = H;
         b.Win = b.Wout = Wd_;
         b.Cin = 64;
@@ -1262,7 +1282,7 @@ struct smi_engine {
     }
     if (save) {
       out_ten = y;
-      last_n = n;
+      bw_n_ad = n_adapted;
       bw_down = lora_down;
       bw_up = lora_up;
       tape_valid = true;
@@ -1285,12 +1305,13 @@ struct smi_engine {
     tens = &tens_[1];
     d_down = dd;
     d_up = du;
-    const int n = last_n, HW = lat_h * lat_w;
+    const int n = bw_n_ad, HW = lat_h * lat_w;  // d_eps covers the adapted samples only
+    n_ad = bw_n_ad;
     Ten* y = out_ten;
     if (!y->ng) return 0;  // adaptor off: nothing depends on the LoRA parameters
     const int64_t cnt = (int64_t)n * cfg.out_channels * HW;
     RUN(launch_grad_scale(d_eps, cnt, gscale, stream));
-    y->g = alloc_t(y->rows, 64);
+    y->g = alloc_t(MA(y), 64);
     RUN(launch_nchw_to_nhwc_scaled(dtype, d_eps, y->g, n, cfg.out_channels, HW, 64, gscale, stream));
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();
     tape.clear();
@@ -1324,10 +1345,11 @@ int check_cfg(const smi_unet_config* c) {
 }
 
 int setup(smi_engine* e, const smi_unet_config* cfg, const smi_weight* weights, int n_weights,
-          const smi_lora_site* sites, int n_sites, int batch, int h, int w, int ctx_len) {
+          const smi_lora_site* sites, int n_sites, int batch, int batch_adapted, int h, int w, int ctx_len) {
   e->cfg = *cfg;
   e->dtype = cfg->dtype;
   e->max_n = batch;
+  e->max_n_ad = batch_adapted;
   e->lat_h = h;
   e->lat_w = w;
   e->ctx_len = ctx_len;
@@ -1344,17 +1366,17 @@ int setup(smi_engine* e, const smi_unet_config* cfg, const smi_weight* weights, 
 }
 
 // dry run: sizes of the three regions
-int plan(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int h, int w, int ctx_len,
-         size_t out[3]) {
+int plan(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int batch_adapted, int h, int w,
+         int ctx_len, size_t out[3]) {
   smi_engine e;
   e.dry = true;
-  setup(&e, cfg, nullptr, 0, sites, n_sites, batch, h, w, ctx_len);
+  setup(&e, cfg, nullptr, 0, sites, n_sites, batch, batch_adapted, h, w, ctx_len);
   e.build();
   if (e.err) return -1;
   out[0] = align_up(e.wpack.peak, 4096);
-  e.forward(batch, nullptr, 0.f, nullptr, nullptr, nullptr, false, nullptr);
+  e.forward(batch, batch_adapted, nullptr, 0.f, nullptr, nullptr, nullptr, false, nullptr);
   out[1] = align_up(e.arena[0].peak, 4096);
-  e.forward(batch, nullptr, 0.f, nullptr, nullptr, nullptr, true, nullptr);
+  e.forward(batch, batch_adapted, nullptr, 0.f, nullptr, nullptr, nullptr, true, nullptr);
   e.backward(nullptr, nullptr, nullptr);
   out[2] = align_up(e.arena[1].peak, 4096);
   return e.err ? -1 : 0;
@@ -1366,28 +1388,30 @@ extern "C" {
 
 const char* smi_last_error(void) { return g_err; }
 
-int smi_workspace_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int h, int w,
-                        int ctx_len, size_t* bytes) {
+int smi_workspace_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch,
+                        int batch_adapted, int h, int w, int ctx_len, size_t* bytes) {
   if (check_cfg(cfg)) return -1;
-  SMI_CHECK(bytes && batch > 0 && h > 0 && w > 0 && ctx_len > 0, "bad arguments");
+  SMI_CHECK(bytes && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
+            "bad arguments");
   size_t r[3];
-  if (plan(cfg, sites, n_sites, batch, h, w, ctx_len, r)) return -1;
+  if (plan(cfg, sites, n_sites, batch, batch_adapted, h, w, ctx_len, r)) return -1;
   *bytes = r[0] + r[1] + r[2] + 3 * 4096;
   return 0;
 }
 
 int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weights, const smi_lora_site* sites,
-               int n_sites, int batch, int h, int w, int ctx_len, void* workspace, size_t workspace_bytes,
-               void* stream, smi_engine** out) {
+               int n_sites, int batch, int batch_adapted, int h, int w, int ctx_len, void* workspace,
+               size_t workspace_bytes, void* stream, smi_engine** out) {
   if (check_cfg(cfg)) return -1;
-  SMI_CHECK(out && workspace && weights && n_weights > 0, "bad arguments");
+  SMI_CHECK(out && workspace && weights && n_weights > 0 && batch_adapted >= 0 && batch_adapted <= batch,
+            "bad arguments");
   size_t r[3];
-  if (plan(cfg, sites, n_sites, batch, h, w, ctx_len, r)) return -1;
+  if (plan(cfg, sites, n_sites, batch, batch_adapted, h, w, ctx_len, r)) return -1;
   SMI_CHECK(r[0] + r[1] + r[2] + 3 * 4096 <= workspace_bytes, "workspace too small: need %zu bytes, got %zu",
             r[0] + r[1] + r[2] + 3 * 4096, workspace_bytes);
   smi_engine* e = new smi_engine();
   e->stream = (hipStream_t)stream;
-  setup(e, cfg, weights, n_weights, sites, n_sites, batch, h, w, ctx_len);
+  setup(e, cfg, weights, n_weights, sites, n_sites, batch, batch_adapted, h, w, ctx_len);
   char* base = (char*)align_up((size_t)workspace, 4096);
   e->ws = (char*)workspace;
   e->ws_bytes = workspace_bytes;
@@ -1412,17 +1436,27 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
 
 void smi_destroy(smi_engine* e) { delete e; }
 
-int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, const void* ctx,
-                     const void* text_embeds, const float* time_ids, const float* lora_down_flat,
-                     const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out) {
+int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* sample, float timestep, const void* ctx,
+                             const void* text_embeds, const float* time_ids, const float* lora_down_flat,
+                             const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out) {
   SMI_CHECK(e && sample && ctx && eps_out, "NULL argument");
   SMI_CHECK(n >= 1 && n <= e->max_n, "batch %d outside [1, %d] the engine was created for", n, e->max_n);
+  SMI_CHECK(n_adapted >= 0 && n_adapted <= n && n_adapted <= e->max_n_ad,
+            "adapted batch %d outside [0, min(%d, %d)]", n_adapted, n, e->max_n_ad);
   SMI_CHECK(!e->cfg.addition_embed || (text_embeds && time_ids), "SD-XL engine needs text_embeds and time_ids");
   e->err = false;
   e->lora_down = lora_down_flat;
   e->lora_up = lora_up_flat;
-  e->mult = (lora_down_flat && lora_up_flat) ? multiplier : 0.f;
-  return e->forward(n, sample, timestep, ctx, text_embeds, time_ids, save_for_backward != 0, eps_out);
+  e->mult = (lora_down_flat && lora_up_flat && n_adapted > 0) ? multiplier : 0.f;
+  return e->forward(n, n_adapted, sample, timestep, ctx, text_embeds, time_ids, save_for_backward != 0, eps_out);
+}
+
+int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, const void* ctx,
+                     const void* text_embeds, const float* time_ids, const float* lora_down_flat,
+                     const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out) {
+  SMI_CHECK(e != nullptr, "NULL argument");
+  return smi_unet_forward_batched(e, n, n < e->max_n_ad ? n : e->max_n_ad, sample, timestep, ctx, text_embeds, time_ids,
+                                  lora_down_flat, lora_up_flat, multiplier, save_for_backward, eps_out);
 }
 
 int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat, float* d_lora_up_flat) {
@@ -1576,7 +1610,7 @@ int smi_op_groupnorm(int dtype, const void* x, const void* gamma, const void* be
   float* part = mr + (size_t)nb * g * 2;
   int rc = launch_groupnorm_fwd(dtype, x, gamma, beta, y, ab, mr, part, nb, hw, c, g, eps, silu, (hipStream_t)stream);
   if (rc || !dy) return rc;
-  return launch_groupnorm_bwd(dtype, x, dy, gamma, beta, ab, mr, nullptr, dx, part, nb, hw, c, g, silu,
+  return launch_groupnorm_bwd(dtype, x, dy, gamma, beta, ab, ab + (size_t)nb * c, mr, nullptr, dx, part, nb, hw, c, g, silu,
                               (hipStream_t)stream);
 }
 int smi_op_layernorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   for (int mi = 0; mi < 4; ++mi) {
     const int m = bm0 + wm * 64 + mi * 16 + fr;
     if (m >= p.M) continue;
-    const float* xrow0 = p.lora_xa + (int64_t)m * p.ld_xa;
+    const bool lora_on = p.lora_r > 0 && m >= p.lora_row0;
+    const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
     const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
       }
-      if (p.lora_r > 0) {
+      if (lora_on) {
         const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

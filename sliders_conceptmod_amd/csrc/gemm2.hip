@@ -169,39 +169,52 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
     if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
     const unsigned char* As = smem + buf * STAGE;
     const unsigned char* Bs = As + BM * BK * 2;
+    // fragments of both 32-deep halves are fetched up front (two register sets) so the second half's LDS latency
+    // hides under the first half's MFMAs
+    typename TT<T>::v8 xa[2][4], wb[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      typename TT<T>::v8 xa[4], wb[4];
       const int ch = kk * 4 + fq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rm = wm * 64 + i * 16 + fr;
         Pack8<T> t;
         t.u = *reinterpret_cast<const u32x4*>(As + rm * 128 + ((ch ^ (rm & 7)) << 4));
-        xa[i] = t.v;
+        xa[kk][i] = t.v;
         const int rn = wn * 64 + i * 16 + fr;
         Pack8<T> s;
         s.u = *reinterpret_cast<const u32x4*>(Bs + rn * 128 + ((ch ^ (rn & 7)) << 4));
-        wb[i] = s.v;
+        wb[kk][i] = s.v;
       }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = TT<T>::mfma16(wb[ni], xa[mi], acc[ni][mi]);
-    }
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = TT<T>::mfma16(wb[kk][ni], xa[kk][mi], acc[ni][mi]);
     __syncthreads();
   }
 
-  // ---- epilogue: per (mi, pair q) the lane holds 8 consecutive columns n = nb + 32q + 8fq + {0..7} of row m
+  // ---- epilogue: per (mi, pair q) the lane holds 8 consecutive columns n = nb + 32q + 8fq + {0..7} of row m.
+  // 16-bit results are staged through LDS (free after the last barrier) and written out as whole rows: one wave
+  // store instruction then covers 4 rows x 256 contiguous bytes instead of 16 rows x 64 bytes -- half-line writes are
+  // cheap while the output fits the Infinity Cache and cost ~2x once it streams to HBM (measured: ff1 at M = 65536).
+  constexpr int OLD = BN + 8;  // LDS row length (elements) of the staged output tile: +16 B pad
+  const bool stage_out = !p.out_f32 && (p.N % 8 == 0);
+  T* otile = reinterpret_cast<T*>(smem);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    const int m = bm0 + wm * 64 + mi * 16 + fr;
+    const int ml = wm * 64 + mi * 16 + fr;
+    const int m = bm0 + ml;
     if (m >= p.M) continue;
-    const float* xrow0 = p.lora_xa + (int64_t)m * p.ld_xa;
+    const bool lora_on = p.lora_r > 0 && m >= p.lora_row0;
+    const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
     const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int n = bn0 + wn * 64 + q * 32 + fq * 8;
+      const int nl = wn * 64 + q * 32 + fq * 8;
+      const int n = bn0 + nl;
       if (n >= p.N) continue;
       float v[8];
 #pragma unroll
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
         v[j] = acc[2 * q][mi][j];
         v[4 + j] = acc[2 * q + 1][mi][j];
       }
-      const bool full = n + 8 <= p.N;  // N % 8 may be 4 (e.g. conv_out): second half masked
+      const bool full = n + 8 <= p.N;  // N % 8 may be 4 (conv_out): second half masked
       if (p.bias) {
         const T* bp = reinterpret_cast<const T*>(p.bias) + n;
         if (full) {
@@ -238,15 +251,41 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
           for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
         }
       }
-      if (p.lora_r > 0) {
+      if (lora_on) {
+        const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
+        if (full && p.up_sq == 1 && p.lora_r == 4 && p.up_sn == 4) {
+          // forward, rank 4: one 16-byte load of xa and one per output column of lora_up [N, 4]
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (n + j < p.N) {
-            const float* xrow = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
-            const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
-            float d = 0.f;
-            for (int r = 0; r < p.lora_r; ++r) d += xrow[r] * up[r * p.up_sq];
-            v[j] += d * p.lora_scale;
+          for (int j = 0; j < 8; ++j) {
+            const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * 4);
+            v[j] += (xv[0] * uv[0] + xv[1] * uv[1] + xv[2] * uv[2] + xv[3] * uv[3]) * p.lora_scale;
+          }
+        } else if (full && p.up_sn == 1 && (p.up_sq & 3) == 0) {
+          // backward (dX): "up" is lora_down [r_tot, K] read along K: 8 consecutive columns = two 16-byte loads per q
+          float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          for (int r = 0; r < p.lora_r; ++r) {
+            const float xq = xrow[r];
+            const float* ar = p.lora_up + (int64_t)r * p.up_sq + n;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              d[j] += xq * a0[j];
+              d[4 + j] += xq * a1[j];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += d[j] * p.lora_scale;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (n + j < p.N) {
+              const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
+              const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
+              float d = 0.f;
+              for (int r = 0; r < p.lora_r; ++r) d += xr[r] * up[r * p.up_sq];
+              v[j] += d * p.lora_scale;
+            }
           }
         }
       }
@@ -268,20 +307,32 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
         float* op = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
         *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
         if (full) *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else if (stage_out) {
+        Pack8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = from_f<T>(v[j]);
+        *reinterpret_cast<u32x4*>(otile + ml * OLD + nl) = o.u;
       } else {
         T* op = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
-        if (full) {
-          Pack8<T> o;
+        Pack4<T> o;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = from_f<T>(v[j]);
-          *reinterpret_cast<u32x4*>(op) = o.u;
-        } else {
-          Pack4<T> o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o.e[j] = from_f<T>(v[j]);
-          *reinterpret_cast<u32x2*>(op) = o.u;
-        }
+        for (int j = 0; j < 4; ++j) o.e[j] = from_f<T>(v[j]);
+        *reinterpret_cast<u32x2*>(op) = o.u;
       }
+    }
+  }
+  if (stage_out) {
+    __syncthreads();
+    constexpr int NT = WM * 128;
+    const int c = tid & 15;         // 16-byte chunk within the 128-column tile row
+    const int n = bn0 + c * 8;
+#pragma unroll
+    for (int i = 0; i < BM / (NT / 16); ++i) {
+      const int r = (tid >> 4) + i * (NT / 16);
+      const int m = bm0 + r;
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) =
+            *reinterpret_cast<const u32x4*>(otile + r * OLD + c * 8);
     }
   }
 }

@@ -37,6 +37,7 @@ struct GemmParams {
   int lora_r = 0;
   int lora_seg = 0;
   float lora_scale = 0.f;
+  int lora_row0 = 0;  // rows m < lora_row0 get no delta (frozen samples of a batched pass); xa row = m - lora_row0
   // implicit-GEMM 3x3 convolution (pad 1)
   int conv = 0;
   int Nb = 0, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0;
@@ -78,6 +79,8 @@ int launch_attn_bwd(const AttnParams& p, hipStream_t stream);
 // GroupNorm over [Nb, HW, C]; writes per-(n,c) affine a,b (f32 [Nb,C] each: y = x*a + b) into `ab` ([2,Nb,C]) and
 // y = (silu?)(x*a+b).  `partial` is scratch f32 [Nb, nchunk, G, 2], nchunk from gn_num_chunks(HW).
 int gn_num_chunks(int HW);
+// ab: [2][Nb][C] -- a = ab, b = ab + Nb*C.  The backward takes the two halves as separate pointers so that it can run
+// on a sample sub-range of a larger forward batch.
 int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* ab,
                          float* mean_rstd, float* partial, int Nb, int HW, int C, int G, float eps, int silu,
                          hipStream_t stream);
@@ -85,8 +88,8 @@ int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void
 // `partial`: scratch f32 [Nb*nchunk*G*2 + 2*Nb*C]
 // `add` (optional, may alias dx): gradient already accumulated for x, added in the same pass
 int launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const void* beta,
-                         const float* ab, const float* mean_rstd, const void* add, void* dx, float* partial, int Nb,
-                         int HW, int C, int G, int silu, hipStream_t stream);
+                         const float* a, const float* b, const float* mean_rstd, const void* add, void* dx,
+                         float* partial, int Nb, int HW, int C, int G, int silu, hipStream_t stream);
 int launch_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean_rstd,
                          int M, int C, float eps, hipStream_t stream);
 int launch_layernorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const float* mean_rstd,

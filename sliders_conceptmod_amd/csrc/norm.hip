@@ -30,8 +30,9 @@ __host__ __device__ inline GnGeom gn_geom(int C) {
 template <typename T, int MODE, bool SILU>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                         const float* __restrict__ ab, float* __restrict__ partial,
-                                                         int Nb, int HW, int C, int G, int nchunk) {
+                                                         const float* __restrict__ aa, const float* __restrict__ bb,
+                                                         float* __restrict__ partial, int Nb, int HW, int C, int G,
+                                                         int nchunk) {
   extern __shared__ float red[];  // [rpar][C][2]
   const GnGeom gg = gn_geom(C);
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   const bool active = rsub < gg.rpar;
   const int row0 = chunk * GN_ROWS_PER_CHUNK;
   const int row1 = min(HW, row0 + GN_ROWS_PER_CHUNK);
-  const float* an = ab + (int64_t)n * C;
-  const float* bn = ab + ((int64_t)Nb + n) * C;
+  const float* an = aa + (int64_t)n * C;  // only dereferenced in MODE 1
+  const float* bn = bb + (int64_t)n * C;
 
   for (int j = 0; j < gg.ncol; ++j) {
     const int col = col_base + 256 * j;
@@ -187,16 +188,17 @@ __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(const float* __res
 // MODE 0: y = silu?(x*a+b).   MODE 1: dx = a*dz + c2*x + c3
 template <typename T, int MODE, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                       const float* __restrict__ ab, const float* __restrict__ cd,
-                                                       const T* add, T* out, int Nb, int HW, int C) {
+                                                       const float* __restrict__ aa, const float* __restrict__ bb,
+                                                       const float* __restrict__ cd, const T* add, T* out, int Nb,
+                                                       int HW, int C) {
   const int cols8 = C / 8;
   const int64_t total = (int64_t)Nb * HW * cols8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int col = (int)(i % cols8);
     const int64_t row = i / cols8;
     const int n = (int)(row / HW);
-    const float* a = ab + (int64_t)n * C + col * 8;
-    const float* b = ab + ((int64_t)Nb + n) * C + col * 8;
+    const float* a = aa + (int64_t)n * C + col * 8;
+    const float* b = bb + (int64_t)n * C + col * 8;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(b), b1 = *reinterpret_cast<const f32x4*>(b + 4);
     Pack8<T> xv, o;
@@ -344,22 +346,22 @@ int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float*
   const GnGeom gg = gn_geom(C);
   const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
   hipLaunchKernelGGL((gn_partial_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x, nullptr,
-                     nullptr, nullptr, ab, partial, Nb, HW, C, G, nchunk);
+                     nullptr, nullptr, ab, ab, partial, Nb, HW, C, G, nchunk);
   hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(Nb), dim3(256), G * 2 * sizeof(float), st, partial,
                      (const T*)gamma, (const T*)beta, ab, mean_rstd, Nb, HW, C, G, nchunk, eps);
   const int grid = ew_grid((int64_t)Nb * HW * (C / 8));
   if (silu)
-    hipLaunchKernelGGL((gn_apply_kernel<T, 0, true>), dim3(grid), dim3(256), 0, st, (const T*)x, nullptr, ab, nullptr,
-                       nullptr, (T*)y, Nb, HW, C);
+    hipLaunchKernelGGL((gn_apply_kernel<T, 0, true>), dim3(grid), dim3(256), 0, st, (const T*)x, nullptr, ab,
+                       ab + (size_t)Nb * C, nullptr, nullptr, (T*)y, Nb, HW, C);
   else
     hipLaunchKernelGGL((gn_apply_kernel<T, 0, false>), dim3(grid), dim3(256), 0, st, (const T*)x, nullptr, ab,
-                       nullptr, nullptr, (T*)y, Nb, HW, C);
+                       ab + (size_t)Nb * C, nullptr, nullptr, (T*)y, Nb, HW, C);
   SMI_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T>
-int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta, const float* ab,
+int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta, const float* aa, const float* bb,
              const float* mean_rstd, const void* add, void* dx, float* partial, float* cd, int Nb, int HW, int C,
              int G, int silu, hipStream_t st) {
   const int nchunk = gn_num_chunks(HW);
@@ -367,18 +369,18 @@ int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta,
   const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
   if (silu)
     hipLaunchKernelGGL((gn_partial_kernel<T, 1, true>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x,
-                       (const T*)dy, (const T*)gamma, (const T*)beta, ab, partial, Nb, HW, C, G, nchunk);
+                       (const T*)dy, (const T*)gamma, (const T*)beta, aa, bb, partial, Nb, HW, C, G, nchunk);
   else
     hipLaunchKernelGGL((gn_partial_kernel<T, 1, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x,
-                       (const T*)dy, (const T*)gamma, (const T*)beta, ab, partial, Nb, HW, C, G, nchunk);
+                       (const T*)dy, (const T*)gamma, (const T*)beta, aa, bb, partial, Nb, HW, C, G, nchunk);
   hipLaunchKernelGGL(gn_finalize_bwd_kernel<T>, dim3(Nb), dim3(256), G * 2 * sizeof(float), st, partial, mean_rstd, cd,
                      Nb, HW, C, G, nchunk);
   const int grid = ew_grid((int64_t)Nb * HW * (C / 8));
   if (silu)
-    hipLaunchKernelGGL((gn_apply_kernel<T, 1, true>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, ab, cd,
+    hipLaunchKernelGGL((gn_apply_kernel<T, 1, true>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, aa, bb, cd,
                        (const T*)add, (T*)dx, Nb, HW, C);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<T, 1, false>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, ab,
+    hipLaunchKernelGGL((gn_apply_kernel<T, 1, false>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, aa, bb,
                        cd, (const T*)add, (T*)dx, Nb, HW, C);
   SMI_HIP(hipGetLastError());
   return 0;
@@ -399,13 +401,13 @@ int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void
 
 // `partial` must hold Nb*nchunk*G*2 floats followed by 2*Nb*C floats (the c2/c3 coefficient arrays)
 int launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const void* beta,
-                         const float* ab, const float* mean_rstd, const void* add, void* dx, float* partial, int Nb,
-                         int HW, int C, int G, int silu, hipStream_t stream) {
+                         const float* a, const float* b, const float* mean_rstd, const void* add, void* dx,
+                         float* partial, int Nb, int HW, int C, int G, int silu, hipStream_t stream) {
   SMI_CHECK(C % 8 == 0 && C % G == 0, "groupnorm bwd: C=%d G=%d", C, G);
   float* cd = partial + (size_t)Nb * gn_num_chunks(HW) * G * 2;
   return dtype == DT_F16
-             ? gn_bwd_t<f16>(x, dy, gamma, beta, ab, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream)
-             : gn_bwd_t<bf16>(x, dy, gamma, beta, ab, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream);
+             ? gn_bwd_t<f16>(x, dy, gamma, beta, a, b, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream)
+             : gn_bwd_t<bf16>(x, dy, gamma, beta, a, b, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream);
 }
 
 int launch_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean_rstd,

@@ -25,7 +25,7 @@ from . import _native, parallel
 class SliderStep:
     def __init__(self, unet, network, scheduler, *, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, max_grad_norm: float = 0.0, cfg_scale: float = 1.0,
-                 skip_dead_cfg_half: bool = False, process_group=None):
+                 skip_dead_cfg_half: bool = False, process_group=None, batch_passes: bool = True):
         self.unet, self.network, self.scheduler = unet, network, scheduler
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -34,6 +34,9 @@ class SliderStep:
         # Off by default: the reference computes it, so the headline number does too.
         self.skip_dead = bool(skip_dead_cfg_half and cfg_scale == 1.0)
         self.pg = process_group
+        # Run the four guidance passes as ONE UNet pass (frozen samples first, adapted target samples last;
+        # smi_unet_forward_batched): same per-sample arithmetic, 4x larger GEMM M, ~60 % fewer launches.
+        self.batch_passes = batch_passes
         flat = network.flat
         self.grad = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat)
@@ -66,6 +69,8 @@ class SliderStep:
                 c["text_embeds"] = pe.to(dev, dt).contiguous()
                 c["time_ids"] = ti.to(dev, torch.float32).contiguous()
             out[role] = c
+        order = ("positive", "neutral", "negative", "target")  # adapted (target) samples LAST
+        out["all"] = {k: torch.cat([out[r][k] for r in order]).contiguous() for k in out["target"]}
         return out
 
     def _pass(self, engine, x, t, c, lora: bool, save: bool):
@@ -90,8 +95,10 @@ class SliderStep:
         x = self.scheduler.scale_model_input(x, timestep).contiguous()
         t = float(timestep)
         n, _, h, w = x.shape
-        engine = self.unet._ensure_engine(n, h, w, cond["target"]["ctx"].shape[1])
+        engine = None if self.batch_passes else self.unet._ensure_engine(n, h, w, cond["target"]["ctx"].shape[1])
         net = self.network
+        if self.batch_passes:
+            return self._train_step_batched(x, t, cond, action, eta, lr)
         net.__exit__(None, None, None)
         positive = self._pass(engine, x, t, cond["positive"], False, False)
         neutral = self._pass(engine, x, t, cond["neutral"], False, False)
@@ -100,6 +107,34 @@ class SliderStep:
         target = self._pass(engine, x, t, cond["target"], True, True)
         net.__exit__(None, None, None)
 
+        return self._finish(engine, target, positive, neutral, negative, action, eta, lr)
+
+    def _train_step_batched(self, x, t, cond, action, eta, lr):
+        net = self.network
+        n, _, h, w = x.shape
+        engine = self.unet._ensure_engine(4 * n, h, w, cond["target"]["ctx"].shape[1], n_adapted=n)
+        net.__enter__()
+        flat, n_down, mult = net.engine_params()
+        net.__exit__(None, None, None)
+        c = cond["all"]
+        x4 = torch.cat([x] * 4)
+        eps = engine.forward(x4, t, c["ctx"], c.get("text_embeds"), c.get("time_ids"), flat[:n_down], flat[n_down:],
+                             mult, True, n_adapted=n)
+        outs = []
+        for i in range(4):
+            e = eps[i * n:(i + 1) * n]
+            if self.skip_dead:
+                outs.append(e)
+            else:
+                o = torch.empty((n // 2,) + tuple(e.shape[1:]), dtype=torch.float32, device=e.device)
+                _native.check(self._lib.smi_cfg_combine(_native.ptr(e), _native.ptr(o), o.numel(), self.cfg_scale,
+                                                        _native.stream_ptr()), "smi_cfg_combine")
+                outs.append(o)
+        positive, neutral, negative, target = outs
+        return self._finish(engine, target, positive, neutral, negative, action, eta, lr)
+
+    def _finish(self, engine, target, positive, neutral, negative, action, eta, lr):
+        net = self.network
         sign_eta = eta if action == "enhance" else -eta
         if action not in ("enhance", "erase"):
             raise ValueError("action must be erase or enhance")

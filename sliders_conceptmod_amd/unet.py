@@ -277,12 +277,15 @@ class UNet2DConditionModel(nn.Module):
     def device(self):
         return self.conv_in.weight.device
 
-    def _ensure_engine(self, n, h, w, ctx_len):
+    def _ensure_engine(self, n, h, w, ctx_len, n_adapted=None):
+        """Engine for UNet batch n of which n_adapted (default n) samples may be LoRA-adapted / differentiated."""
+        n_adapted = n if n_adapted is None else n_adapted
         net = self._lora_network
         sites = net.engine_sites() if net is not None else []
         key = (self.dtype, str(self.device), h, w, ctx_len, tuple((s["target"], s["off_down"], s["off_up"], s["rank"],
                                                                    s["scale"]) for s in sites))
-        if self._engine is not None and self._engine_key == key and n <= self._engine.batch:
+        if (self._engine is not None and self._engine_key == key and n <= self._engine.batch
+                and n_adapted <= self._engine.batch_adapted):
             return self._engine
         if self.device.type != "cuda":
             raise _native.SmiError("the UNet runs only on an MI355X through the HIP engine; move it to a cuda "
@@ -291,10 +294,12 @@ class UNet2DConditionModel(nn.Module):
             raise _native.SmiError(f"engine dtypes are float16/bfloat16, got {self.dtype}")
         if self._engine is not None:
             n = max(n, self._engine.batch)
+            n_adapted = max(n_adapted, self._engine.batch_adapted)
             self._engine.close()
             self._engine = None
         state = {k: v.detach() for k, v in self.state_dict().items()}
-        self._engine = _native.Engine(self.cfg, self.dtype, state, sites, n, h, w, ctx_len, self.device)
+        self._engine = _native.Engine(self.cfg, self.dtype, state, sites, n, h, w, ctx_len, self.device,
+                                      batch_adapted=min(n, n_adapted))
         self._engine_key = key
         return self._engine
 

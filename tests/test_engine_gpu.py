@@ -164,3 +164,46 @@ def test_smaller_batch_than_engine_capacity():
         sub = pu(x[:2].cuda(), 300.0, encoder_hidden_states=ctx[:2].cuda(),
                  added_cond_kwargs={k: v[:2].cuda() for k, v in add.items()}).sample
     torch.testing.assert_close(sub, full[:2], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+def test_batched_guidance_pass_equals_separate_passes(model):
+    """smi_unet_forward_batched: [frozen | frozen | frozen | adapted] in one pass == four passes, bit for bit,
+    forward and LoRA gradients (per-sample arithmetic does not depend on the batch composition)."""
+    ocfg, ou, onet, pu, pnet = build_pair(model, torch.float16)
+    n = 2
+    xs, ctxs, adds = [], [], []
+    for i in range(4):
+        x, ctx, add = inputs(ocfg, n, 16, seed=3)
+        _, ctx, add2 = inputs(ocfg, n, 16, seed=10 + i)
+        xs.append(x), ctxs.append(ctx), adds.append(add2)
+    flat, n_down, _ = pnet.engine_params()
+    down, up = flat[:n_down].detach(), flat[n_down:].detach()
+    dt = torch.float16
+
+    def te(a, k):
+        return None if a is None else (a[k].cuda().to(dt) if k == "text_embeds" else a[k].cuda().float())
+
+    gy = torch.randn(n, 4, 16, 16, generator=torch.Generator().manual_seed(9)).cuda() * 1e-3
+    # four separate passes (engine capacity n, all adapted)
+    eng = pu._ensure_engine(n, 16, 16, 77)
+    sep = []
+    for i in range(4):
+        lora = i == 3
+        sep.append(eng.forward(xs[i].cuda(), 499.0, ctxs[i].cuda().to(dt), te(adds[i], "text_embeds"),
+                               te(adds[i], "time_ids"), down if lora else None, up if lora else None,
+                               1.0 if lora else 0.0, lora))
+    g_sep = torch.zeros_like(flat)
+    eng.backward(gy, g_sep[:n_down], g_sep[n_down:])
+    # one batched pass
+    eng4 = pu._ensure_engine(4 * n, 16, 16, 77, n_adapted=n)
+    cat = lambda ts: None if ts[0] is None else torch.cat(ts).contiguous()
+    out = eng4.forward(torch.cat(xs).cuda(), 499.0, torch.cat(ctxs).cuda().to(dt),
+                       cat([te(a, "text_embeds") for a in adds]), cat([te(a, "time_ids") for a in adds]), down, up, 1.0,
+                       True, n_adapted=n)
+    g_bat = torch.zeros_like(flat)
+    eng4.backward(gy, g_bat[:n_down], g_bat[n_down:])
+    for i in range(4):
+        torch.testing.assert_close(out[i * n:(i + 1) * n], sep[i], rtol=0, atol=0)
+    assert float(g_sep.abs().max()) > 0
+    torch.testing.assert_close(g_bat, g_sep, rtol=0, atol=0)
