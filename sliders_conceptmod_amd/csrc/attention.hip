@@ -5,8 +5,10 @@
 // max / sum are register reductions plus a single cross-half exchange, and the f32 accumulator tile, converted
 // pairwise to 16-bit, is already the B operand of the next product (O^T = V^T . P^T) -- no LDS round trip for P
 // (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").  The A operand of that
-// product needs V with the key index contiguous, so V (and K / Q / dO in the backward) is staged into LDS both
-// row-major and transposed.  LDS rows are padded (+16 B / +8 B) so fragment reads are bank-conflict free.
+// product needs V with the key index contiguous: V (and K / Q / dO in the backward) is staged row-major with 16-byte
+// stores and read TRANSPOSED by the gfx950 `ds_read_b64_tr_b16` instruction (4 keys x 16 columns per 16-lane group,
+// delivered column-major) -- no scatter writes.  Row strides are chosen so that both the row reads (ds_read_b128,
+// stride D+8 elements) and the transposed reads (stride = 64 or 192 bytes mod 256) are bank-conflict free.
 //
 // Backward (activations only: dQ, and dK/dV when a LoRA hangs off to_k/to_v) recomputes P from Q, K and the
 // forward's log-sum-exp; it is split into a dQ kernel (one workgroup per 128 queries, sweeping keys) and a dK/dV
@@ -18,11 +20,15 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int TK = 64;   // keys (or queries) per staged tile
-constexpr int LDT = 68;  // row length (elements) of transposed tiles [d][64 + 4]
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// row length (elements) of tiles read with ds_read_b64_tr_b16: a 32-lane half reads 4 rows x 64 contiguous bytes, so
+// the byte stride must be 64 or 192 (mod 256) for the four row segments to fall on disjoint banks
+__host__ __device__ constexpr int tr_stride(int DP) { return ((DP * 2) % 128 == 64) ? DP : DP + 32; }
 
 template <typename T, int DP>
 struct Stage {
-  static constexpr int LDN = DP + 8;   // row length of natural tiles [64][DP + 8]
+  static constexpr int LDN = DP + 8;   // row length of tiles read by rows (ds_read_b128)
+  static constexpr int LDV = tr_stride(DP);  // row length of tiles read transposed (ds_read_b64_tr_b16)
   static constexpr int NIT = DP / 32;  // 16-byte chunks per thread per tile (64 * DP/8 / 256)
   static constexpr int CPR = DP / 8;   // chunks per row
 
@@ -46,15 +52,12 @@ struct Stage {
       *reinterpret_cast<u32x4*>(dst + row * LDN + ch * 8) = reg[i];
     }
   }
-  static __device__ __forceinline__ void store_tr(const u32x4 (&reg)[NIT], T* dst, int tid) {
+  static __device__ __forceinline__ void store_ld(const u32x4 (&reg)[NIT], T* dst, int ld, int tid) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int idx = tid + 256 * i;
       const int row = idx / CPR, ch = idx - row * CPR;
-      Pack8<T> t;
-      t.u = reg[i];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dst[(ch * 8 + e) * LDT + row] = t.e[e];
+      *reinterpret_cast<u32x4*>(dst + row * ld + ch * 8) = reg[i];
     }
   }
 };
@@ -72,14 +75,23 @@ __device__ __forceinline__ typename TT<T>::v8 ld_frag_nat(const T* tile, int ldn
   t.u = *reinterpret_cast<const u32x4*>(tile + row * ldn + col);
   return t.v;
 }
-// A-operand fragment from a transposed tile Xt[d][idx]: elements j<4 at idx0 + j, j>=4 at idx0 + 8 + (j-4)
+// A-operand fragment X^T[d = d0 + (lane & 31)][k] from a ROW-MAJOR tile X[idx][d] through the hardware transposed
+// read: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a 4 x 16 block and lane i
+// receives column i (rows 0..3 in elements 0..3).  Elements j < 4 come from rows idx0 + j, j >= 4 from idx0 + 8 + (j-4)
+// (the k order of an accumulator tile used as the other operand); idx0 already contains 4 * (lane >> 5).
 template <typename T>
-__device__ __forceinline__ typename TT<T>::v8 ld_frag_tr(const T* tile, int d, int idx0) {
-  Pack8<T> t;
-  const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + d * LDT + idx0);
-  const u32x2 hi = *reinterpret_cast<const u32x2*>(tile + d * LDT + idx0 + 8);
-  t.u = u32x4{lo[0], lo[1], hi[0], hi[1]};
-  return t.v;
+__device__ __forceinline__ typename TT<T>::v8 ld_frag_trhw(const T* tile, int ld, int idx0, int d0, int lane) {
+  const T* a = tile + (idx0 + ((lane & 15) >> 2)) * ld + d0 + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 8 * ld));
+  union {
+    s16x4 h[2];
+    typename TT<T>::v8 v;
+  } u;
+  u.h[0] = lo;
+  u.h[1] = hi;
+  return u.v;
 }
 __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
 
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
   __shared__ __attribute__((aligned(16))) T Ks[TK * S::LDN];
-  __shared__ __attribute__((aligned(16))) T Vt[DP * LDT];
+  __shared__ __attribute__((aligned(16))) T Vs[TK * S::LDV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, h2 = lane >> 5;
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     S::load(rv, rV, k0, p.Nk, p.ldv, col0, p.D, tid);
     __syncthreads();  // previous tile fully consumed
     S::store_nat(rk, Ks, tid);
-    S::store_tr(rv, Vt, tid);
+    S::store_ld(rv, Vs, S::LDV, tid);
     __syncthreads();
 
     f32x16 st[2];
@@ -146,16 +158,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         }
       }
     }
-    // mask keys beyond Nk, tile max
+    // mask keys beyond Nk (ragged last tile only), tile max
+    if (k0 + TK > p.Nk) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + sub * 32 + acc_row(r, h2) >= p.Nk) st[sub][r] = -INFINITY;
+    }
     float mloc = -INFINITY;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + sub * 32 + acc_row(r, h2);
-        if (key >= p.Nk) st[sub][r] = -INFINITY;
-        mloc = fmaxf(mloc, st[sub][r]);
-      }
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[sub][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m_run, mloc);
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl);
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         const int kb = sub * 32 + s2 * 16 + 4 * h2;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          const auto vf = ld_frag_tr<T>(Vt, i * 32 + ql, kb);
+          const auto vf = ld_frag_trhw<T>(Vs, S::LDV, kb, i * 32, lane);
           o[i] = TT<T>::mfma32(vf, pf, o[i]);
         }
       }
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int NS = DP / 16, NB = DP / 32;
   __shared__ __attribute__((aligned(16))) T Ks[TK * S::LDN];
   __shared__ __attribute__((aligned(16))) T Vs[TK * S::LDN];
-  __shared__ __attribute__((aligned(16))) T Kt[DP * LDT];
+  __shared__ __attribute__((aligned(16))) T Ks2[TK * S::LDV];  // K again, at the transposed-read stride
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, h2 = lane >> 5;
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     S::load(rv, rV, k0, p.Nk, p.ldv, col0, p.D, tid);
     __syncthreads();
     S::store_nat(rk, Ks, tid);
-    S::store_tr(rk, Kt, tid);
+    S::store_ld(rk, Ks2, S::LDV, tid);
     S::store_nat(rv, Vs, tid);
     __syncthreads();
 #pragma unroll
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         const int kb = sub * 32 + s2 * 16 + 4 * h2;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          const auto kf = ld_frag_tr<T>(Kt, i * 32 + ql, kb);
+          const auto kf = ld_frag_trhw<T>(Ks2, S::LDV, kb, i * 32, lane);
           dq[i] = TT<T>::mfma32(kf, df, dq[i]);
         }
       }
@@ -359,9 +374,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   T* Qs = reinterpret_cast<T*>(dyn_smem);
   T* Gs = Qs + TK * S::LDN;
-  T* Qt = Gs + TK * S::LDN;
-  T* Gt = Qt + DP * LDT;
-  float* lse_s = reinterpret_cast<float*>(Gt + DP * LDT);
+  T* Qs2 = Gs + TK * S::LDN;  // Q and dO again, at the transposed-read stride
+  T* Gs2 = Qs2 + TK * S::LDV;
+  float* lse_s = reinterpret_cast<float*>(Gs2 + TK * S::LDV);
   float* dlt_s = lse_s + TK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -415,8 +430,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     __syncthreads();
     S::store_nat(rq, Qs, tid);
     S::store_nat(rg, Gs, tid);
-    if (DO_DK) S::store_tr(rq, Qt, tid);
-    if (DO_DV) S::store_tr(rg, Gt, tid);
+    if (DO_DK) S::store_ld(rq, Qs2, S::LDV, tid);
+    if (DO_DV) S::store_ld(rg, Gs2, S::LDV, tid);
     if (tid < TK) {
       lse_s[tid] = lv;
       dlt_s[tid] = dl;
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
           const auto pf = pack8<T>(st, s2);
 #pragma unroll
           for (int i = 0; i < NB; ++i) {
-            const auto ga = ld_frag_tr<T>(Gt, i * 32 + kl, qb);
+            const auto ga = ld_frag_trhw<T>(Gs2, S::LDV, qb, i * 32, lane);
             dv[i] = TT<T>::mfma32(ga, pf, dv[i]);
           }
         }
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
           const auto df = pack8<T>(dp, s2);
 #pragma unroll
           for (int i = 0; i < NB; ++i) {
-            const auto qa = ld_frag_tr<T>(Qt, i * 32 + kl, qb);
+            const auto qa = ld_frag_trhw<T>(Qs2, S::LDV, qb, i * 32, lane);
             dk[i] = TT<T>::mfma32(qa, df, dk[i]);
           }
         }
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 
 template <typename T, int DP>
 size_t dkv_smem() {
-  return (size_t)(2 * TK * Stage<T, DP>::LDN + 2 * DP * LDT) * sizeof(T) + 2 * TK * sizeof(float);
+  return (size_t)(2 * TK * Stage<T, DP>::LDN + 2 * TK * Stage<T, DP>::LDV) * sizeof(T) + 2 * TK * sizeof(float);
 }
 
 int check_attn(const AttnParams& p) {

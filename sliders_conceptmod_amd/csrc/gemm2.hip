@@ -63,8 +63,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   // ---- per-lane source rows.  Wave w issues A instructions j = 0..A_INSTR-1 covering tile rows
   //      (w*A_INSTR + j)*8 + (lane>>3); lane slot (lane&7) holds source chunk slot ^ (row & 7).
   const int lrow = lane >> 3, lslot = lane & 7;
-  const T* a_ptr[A_INSTR];   // dense: row base pointer (or null -> zero page)
+  const T* a_ptr[A_INSTR];   // dense: row base pointer (or null -> zero page); conv fast path: centre-tap pointer
   int c_base[A_INSTR], c_oy[A_INSTR], c_ox[A_INSTR];
+  // plain 3x3 / stride 1 convs (all but 5 launches per pass): the tap only adds a wave-uniform element offset
+  const bool conv_fast = CONV && p.stride == 1 && !p.upsample && !p.transposed;
   int a_chunk[A_INSTR];
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
         c_oy[j] = -(1 << 20);
         c_ox[j] = -(1 << 20);
       }
-      a_ptr[j] = nullptr;
+      a_ptr[j] = Ap + ((int64_t)(c_base[j] + c_oy[j] * p.Win + c_ox[j]) * p.Cin + a_chunk[j] * 8);
     } else {
       a_ptr[j] = (m < p.M) ? Ap + (int64_t)m * p.lda : nullptr;
     }
@@ -111,6 +113,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
       const int tap = k0 / p.Cin;
       const int c0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
+      if (conv_fast) {
+        const int toff = ((ky - 1) * p.Win + (kx - 1)) * p.Cin + c0;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) {
+          const int iy = c_oy[j] + ky - 1, ix = c_ox[j] + kx - 1;
+          const bool ok = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
+          const void* src = ok ? (const void*)(a_ptr[j] + toff) : (const void*)zero;
+          glds16(src, As + (wave * A_INSTR + j) * 1024);
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < A_INSTR; ++j) {
         int iy, ix;
@@ -376,8 +388,11 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
   int wm = 2;
   if (variant == 2) wm = 4;
   else if (variant == 0) {
+    // measured (tools/bench_gemm.py): the 256-row tile only pays for very wide outputs (N >= 4096: fewer LDS bytes
+    // staged per FLOP); at small N or short K the 128-row tile's extra resident workgroup per CU wins
     const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, BN);
-    if (tiles256 >= 512) wm = 4;
+    if (tiles256 >= 512 && p.N >= 4096 && !p.conv) wm = 4;
+    if (p.conv && tiles256 >= 512) wm = 4;
   }
 #define GO(TT_, CV, W_) return launch_t<TT_, CV, W_>(p, stream)
   if (p.dtype == DT_F16) {
