@@ -12,6 +12,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsmi_hip.so")
 SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "norm.hip", "elementwise.hip", "lora.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# attention: the softmax works on MFMA results every tile; with the default AGPR-form MFMA hipcc shuttles every
+# accumulator through v_accvgpr_read/write (481 moves per key tile, the kernel was VALU-bound at 91 % VALU busy).
+# gfx950's unified register file lets MFMA accumulate in VGPRs directly.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale(target, deps):
@@ -34,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -135,15 +135,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const float sl = p.scale * LOG2E;
 
   const int ntiles = (p.Nk + TK - 1) / TK;
+  // K/V tiles are fetched one tile ahead into registers: the global-load latency hides under the MFMAs / softmax
+  u32x4 rk[S::NIT], rv[S::NIT];
+  S::load(rk, rK, 0, p.Nk, p.ldk, col0, p.D, tid);
+  S::load(rv, rV, 0, p.Nk, p.ldv, col0, p.D, tid);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * TK;
-    u32x4 rk[S::NIT], rv[S::NIT];
-    S::load(rk, rK, k0, p.Nk, p.ldk, col0, p.D, tid);
-    S::load(rv, rV, k0, p.Nk, p.ldv, col0, p.D, tid);
     __syncthreads();  // previous tile fully consumed
     S::store_nat(rk, Ks, tid);
     S::store_ld(rv, Vs, S::LDV, tid);
     __syncthreads();
+    if (kt + 1 < ntiles) {
+      S::load(rk, rK, k0 + TK, p.Nk, p.ldk, col0, p.D, tid);
+      S::load(rv, rV, k0 + TK, p.Nk, p.ldv, col0, p.D, tid);
+    }
 
     f32x16 st[2];
 #pragma unroll
@@ -298,16 +303,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
   const int ntiles = (p.Nk + TK - 1) / TK;
+  u32x4 rk[S::NIT], rv[S::NIT];  // one tile ahead (see forward)
+  S::load(rk, rK, 0, p.Nk, p.ldk, col0, p.D, tid);
+  S::load(rv, rV, 0, p.Nk, p.ldv, col0, p.D, tid);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * TK;
-    u32x4 rk[S::NIT], rv[S::NIT];
-    S::load(rk, rK, k0, p.Nk, p.ldk, col0, p.D, tid);
-    S::load(rv, rV, k0, p.Nk, p.ldv, col0, p.D, tid);
     __syncthreads();
     S::store_nat(rk, Ks, tid);
     S::store_ld(rk, Ks2, S::LDV, tid);
     S::store_nat(rv, Vs, tid);
     __syncthreads();
+    if (kt + 1 < ntiles) {
+      S::load(rk, rK, k0 + TK, p.Nk, p.ldk, col0, p.D, tid);
+      S::load(rv, rV, k0 + TK, p.Nk, p.ldv, col0, p.D, tid);
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 st, dp;
@@ -416,17 +425,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) dv[i][r] = 0.f;
 
   const int ntiles = (p.Nq + TK - 1) / TK;
-  for (int qt = 0; qt < ntiles; ++qt) {
-    const int q0 = qt * TK;
-    u32x4 rq[S::NIT], rg[S::NIT];
+  u32x4 rq[S::NIT], rg[S::NIT];  // Q / dO tiles one tile ahead in registers
+  float lv = 0.f, dl = 0.f;
+  auto fetch = [&](int q0) {
     S::load(rq, rQ, q0, p.Nq, p.ldq, col0, p.D, tid);
     S::load(rg, rG, q0, p.Nq, p.lddo, col0, p.D, tid);
-    float lv = 0.f, dl = 0.f;
     if (tid < TK) {
       const bool ok = q0 + tid < p.Nq;
       lv = ok ? p.lse[stat0 + q0 + tid] * LOG2E : INFINITY;  // +inf -> P = 0 for padded queries
       dl = ok ? p.delta[stat0 + q0 + tid] : 0.f;
     }
+  };
+  fetch(0);
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int q0 = qt * TK;
     __syncthreads();
     S::store_nat(rq, Qs, tid);
     S::store_nat(rg, Gs, tid);
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       dlt_s[tid] = dl;
     }
     __syncthreads();
+    if (qt + 1 < ntiles) fetch(q0 + TK);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 st, dp;

@@ -1,0 +1,76 @@
+"""Parity of the REAL architectures (SD-1.x: 320/640/1280/1280, head_dim 40/80/160, conv proj_in/out;
+SD-XL: 320/640/1280, transformer depth 1/2/10, head_dim 64, text_time conditioning) at reduced resolution
+(256x256 px = 32x32 latents) so the CPU oracle finishes in about a minute on the GPU box's 16-core share.
+fp16 engine vs fp32 oracle; bars are the storage-noise floor (see test_engine_gpu.py) for the deeper networks."""
+import dataclasses
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import slider_ref as R
+from oracle import unet_ref as OU
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("model", ["sd1x", "sdxl"])
+def test_real_architecture_forward_and_lora_gradients(model):
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.unet as PU
+    torch.set_num_threads(16)
+    ocfg = {"sd1x": OU.sd1x_config, "sdxl": OU.sdxl_config}[model]()
+    ou = OU.init_synthetic_(OU.UNet2DConditionModel(ocfg), seed=0).requires_grad_(False).eval()
+    pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(ocfg)))
+    pu.load_state_dict(ou.state_dict())
+    pu = pu.to("cuda", torch.float16).requires_grad_(False).eval()
+    torch.manual_seed(1)
+    onet = R.LoRANetworkRef(ou, 4, 1.0, 1.0, "noxattn")
+    torch.manual_seed(1)
+    pnet = L.LoRANetwork(pu, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    assert len(pnet.unet_loras) == {"sd1x": 64, "sdxl": 280}[model]
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+            w = torch.randn(lo.lora_up.weight.shape, generator=g) * 0.02
+            lo.lora_up.weight.copy_(w)
+            lp.lora_up.weight.copy_(w)
+    pnet.to("cuda")
+    n, hw = 2, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 4, hw, hw, generator=g)
+    ctx = torch.randn(n, 77, ocfg.cross_attention_dim, generator=g)
+    add = None
+    if model == "sdxl":
+        add = {"text_embeds": torch.randn(n, 1280, generator=g),
+               "time_ids": torch.tensor([[256.0, 256, 0, 0, 256, 256]] * n)}
+    cadd = None if add is None else {k: v.cuda() for k, v in add.items()}
+    gy = torch.randn(n, 4, hw, hw, generator=g) * 1e-4
+    # frozen pass
+    onet.__exit__(None, None, None), pnet.__exit__(None, None, None)
+    with torch.no_grad():
+        ref0 = ou(x, 499.0, ctx, add).sample
+        got0 = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cadd).sample
+    e0 = rel(got0, ref0)
+    # adapted pass + gradients
+    with onet:
+        ref = ou(x, 499.0, ctx, add).sample
+    (ref * gy).sum().backward()
+    with pnet:
+        got = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cadd).sample
+    (got * gy.cuda()).sum().backward()
+    e1 = rel(got, ref)
+    num = den = 0.0
+    for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+        for a, b in ((lp.lora_down.grad, lo.lora_down.weight.grad), (lp.lora_up.grad, lo.lora_up.weight.grad)):
+            num += float((a.cpu() - b).norm() ** 2)
+            den += float(b.norm() ** 2)
+    eg = (num / den) ** 0.5
+    print(f"{model}: eps rel err frozen {e0:.2e}, adapted {e1:.2e}; global LoRA-grad rel err {eg:.2e}")
+    assert e0 < 3e-3 and e1 < 3e-3, (e0, e1)
+    assert rel(got, got0) > 1e-4  # the adaptor does something
+    assert eg < 1.5e-2, eg
