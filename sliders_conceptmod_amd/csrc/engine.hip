@@ -756,7 +756,7 @@ struct smi_engine {
       const int r = L->rank;
       const int rp = L->rows_pad;
       dxa = alloc_f32((size_t)M * rp);
-      float* scratch = alloc_f32(std::max(lora_wgrad_scratch_floats(M, cs, r), lora_wgrad_scratch_floats(M, L->in, r)));
+      float* scratch = alloc_f32(std::max(lora_wgrad_scratch_floats(M, cs, r), lora_wgrad_scratch_floats(M, L->in, rtot)));
       {  // dxa[M, rows_pad] = dy * upT^T : one MFMA GEMM against the block-diagonal 16-bit shadow of lora_up
         GemmParams g;
         g.dtype = dtype;
@@ -777,10 +777,16 @@ struct smi_engine {
         RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, xa + s * r, rp, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
                               cs, r, lscale, gscale + 1, scratch, stream));
       }
-      for (int s = 0; s < L->nseg; ++s) {
-        // d(down_s)[q][k] += lscale/S * sum_m dxa[m][s*r+q] * x[m][k]
-        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, L->rows_pad, PA(x), x->cols, d_down + L->off_down + (int64_t)s * r * L->in,
-                              L->in, 1, M, L->in, r, lscale, gscale + 1, scratch, stream));
+      // d(down)[q'][k] += lscale/S * sum_m dxa[m][q'] * x[m][k] for all fused segments at once: the down matrices of
+      // a fused projection are one contiguous [r_tot, in] block, so x is read once (r_tot <= 32)
+      if (rtot <= 32) {
+        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa, L->rows_pad, PA(x), x->cols, d_down + L->off_down, L->in, 1, M,
+                              L->in, rtot, lscale, gscale + 1, scratch, stream));
+      } else {
+        for (int s = 0; s < L->nseg; ++s)
+          RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, L->rows_pad, PA(x), x->cols,
+                                d_down + L->off_down + (int64_t)s * r * L->in, L->in, 1, M, L->in, r, lscale, gscale + 1,
+                                scratch, stream));
       }
     }
     if (x->ng) {
@@ -861,6 +867,55 @@ struct smi_engine {
       });
     }
     return y;
+  }
+
+  // ff.net.0 (GEGLU): proj = x W^T + b ; out = proj[:, :4C] * gelu(proj[:, 4C:]) as ONE GEMM whose epilogue applies the
+  // gate; the projection is written only for the adapted rows (the backward's geglu_bwd needs it).
+  Ten* linear_geglu(Ten* x, const Lin& L) {
+    GemmParams p;
+    p.dtype = dtype;
+    p.A = x->p;
+    p.lda = x->cols;
+    p.W = L.W;
+    p.ldc = L.out;
+    p.M = (int)x->rows;
+    p.N = L.out;
+    p.K = L.in;
+    p.bias = L.b;
+    const bool need_proj = saving && x->ng;
+    p.geglu_out = reinterpret_cast<void*>(16);  // placeholder for the capability query
+    p.C = reinterpret_cast<void*>(16);
+    if (lora_active(L) || !(dry || gemm_geglu_supported(p))) return geglu(linear(x, L));  // generic path
+    Ten* out = new_ten(x->rows, L.out / 2, x->n, x->H, x->W);
+    p.geglu_out = out->p;
+    // the projection buffer holds the adapted rows only; virtual base so that row m lands at (m - arow0)
+    tens->emplace_back();
+    Ten* pj = &tens->back();
+    *pj = *x;
+    pj->cols = L.out;
+    pj->g = nullptr;
+    char* pbuf = (char*)arena_alloc((size_t)(need_proj ? MA(x) : 1) * L.out * esz());
+    pj->p = pbuf - (size_t)x->arow0 * L.out * esz();
+    p.C = pj->p;
+    p.geglu_row0 = need_proj ? (int)x->arow0 : p.M;
+    RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + 0.5 * (double)p.M * p.N),
+         launch_gemm(p, stream));
+    out->ng = x->ng;
+    pj->ng = x->ng;
+    if (saving && out->ng) {
+      const Lin* Lp = &L;
+      const int C4 = L.out / 2;
+      tape.push_back([=]() {  // linear backward (runs after the GEGLU backward below has produced pj->g)
+        linear_bwd(x, Lp, nullptr, pj, nullptr, false, 0.f);
+      });
+      tape.push_back([=]() {
+        if (!out->g) return;
+        bool had;
+        void* dp = grad_slot(pj, had);
+        RUNP(SMI_PROF_ELEM, 0.0, 10.0 * MA(pj) * C4, launch_geglu_bwd(dtype, PA(pj), out->g, dp, (int)MA(pj), C4, stream));
+      });
+    }
+    return out;
   }
 
   Ten* geglu(Ten* pj) {
@@ -1121,8 +1176,7 @@ struct smi_engine {
       }
       h = linear(o, tb.out2, h);
       nrm = layernorm(h, tb.n3);
-      Ten* pj = linear(nrm, tb.ff1);
-      Ten* gg = geglu(pj);
+      Ten* gg = linear_geglu(nrm, tb.ff1);
       h = linear(gg, tb.ff2, h);
     }
     return linear(h, t.proj_out, x);

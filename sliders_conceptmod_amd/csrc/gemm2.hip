@@ -55,6 +55,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   }
   const int bm0 = (wg / nbn) * BM;
   const int bn0 = (wg % nbn) * BN;
+  const bool geglu = p.geglu_out != nullptr;
+  const int nhalf = p.N >> 1;
+  // tile-local column nl (0..127) -> global output column
+  auto gcol = [&](int nl) { return geglu ? (nl < 64 ? (bn0 >> 1) + nl : nhalf + (bn0 >> 1) + nl - 64) : bn0 + nl; };
 
   const unsigned char* zero = g_zero_page;
   const T* Ap = reinterpret_cast<const T*>(p.A);
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
     // LDS row 64*wn + 16*ni + fr holds W row 64*wn + 32*(ni>>1) + 8*(fr>>2) + 4*(ni&1) + (fr&3); after the MFMAs
     // of the pair (2q, 2q+1) a lane then owns the 8 consecutive columns 32q + 8*fq + {0..7}.
     const int ni_ = (row >> 4) & 3, fr_ = row & 15;
-    const int n = bn0 + (row & 64) + (ni_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (ni_ & 1) + (fr_ & 3);
+    const int n = gcol((row & 64) + (ni_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (ni_ & 1) + (fr_ & 3));
     w_chunk[j] = lslot ^ (row & 7);
     w_ptr[j] = (n < p.N) ? Wp + (int64_t)n * p.K : nullptr;
   }
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int nl = wn * 64 + q * 32 + fq * 8;
-      const int n = bn0 + nl;
+      const int n = gcol(nl);
       if (n >= p.N) continue;
       float v[8];
 #pragma unroll
@@ -333,7 +337,39 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
       }
     }
   }
-  if (stage_out) {
+  if (stage_out && geglu) {
+    __syncthreads();
+    constexpr int NT = WM * 128;
+    {  // hidden * gelu(gate): 8 chunks of 8 output columns per row; a wave writes 8 rows x 128 contiguous bytes
+      const int c = tid & 7;
+      T* gout = reinterpret_cast<T*>(p.geglu_out);
+#pragma unroll
+      for (int i = 0; i < BM / (NT / 8); ++i) {
+        const int r = (tid >> 3) + i * (NT / 8);
+        const int m = bm0 + r;
+        if (m < p.M) {
+          Pack8<T> h, g, o;
+          h.u = *reinterpret_cast<const u32x4*>(otile + r * OLD + c * 8);
+          g.u = *reinterpret_cast<const u32x4*>(otile + r * OLD + 64 + c * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(to_f(h.e[e]) * gelu_f(to_f(g.e[e])));
+          *reinterpret_cast<u32x4*>(gout + (int64_t)m * nhalf + (bn0 >> 1) + c * 8) = o.u;
+        }
+      }
+    }
+    if (bm0 + BM > p.geglu_row0) {  // projection kept only for the rows that will be differentiated
+      const int c = tid & 15;
+      const int n = gcol(c * 8);
+#pragma unroll
+      for (int i = 0; i < BM / (NT / 16); ++i) {
+        const int r = (tid >> 4) + i * (NT / 16);
+        const int m = bm0 + r;
+        if (m < p.M && m >= p.geglu_row0)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) =
+              *reinterpret_cast<const u32x4*>(otile + r * OLD + c * 8);
+      }
+    }
+  } else if (stage_out) {
     __syncthreads();
     constexpr int NT = WM * 128;
     const int c = tid & 15;         // 16-byte chunk within the 128-column tile row
@@ -383,6 +419,11 @@ bool gemm2_supported(const GemmParams& p) {
   return p.N == 4 && p.ldc % 4 == 0 && !p.res && !p.rowvec;  // conv_out: one half-width column group
 }
 
+bool gemm2_geglu_supported(const GemmParams& p) {
+  return gemm2_supported(p) && !p.conv && !p.out_f32 && !p.res && !p.rowvec && p.lora_r == 0 && p.N % 256 == 0 &&
+         (reinterpret_cast<uintptr_t>(p.geglu_out) & 15) == 0;
+}
+
 int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
   // variant: 0 = auto, 1 = 128-row tile, 2 = 256-row tile
   int wm = 2;
@@ -394,13 +435,17 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
     if (tiles256 >= 512 && p.N >= 4096 && !p.conv) wm = 4;
     if (p.conv && tiles256 >= 512) wm = 4;
   }
+  // small grids (e.g. M = 4096 adapted rows x N = 1280 in the backward: 320 tiles of 128x128 for 256 CUs): a 64-row
+  // tile doubles the number of workgroups (3 resident per CU at 48 KB LDS)
+  // (measured: no -- 4096x1280x1280 runs 435 TF/s on 64-row tiles vs 465 on 128-row; kept selectable, SMI_GEMM=64)
+  if (variant == 3) wm = 1;
 #define GO(TT_, CV, W_) return launch_t<TT_, CV, W_>(p, stream)
   if (p.dtype == DT_F16) {
     if (p.conv) { if (wm == 4) GO(f16, true, 4); else GO(f16, true, 2); }
-    else { if (wm == 4) GO(f16, false, 4); else GO(f16, false, 2); }
+    else { if (wm == 4) GO(f16, false, 4); else if (wm == 1) GO(f16, false, 1); else GO(f16, false, 2); }
   } else {
     if (p.conv) { if (wm == 4) GO(bf16, true, 4); else GO(bf16, true, 2); }
-    else { if (wm == 4) GO(bf16, false, 4); else GO(bf16, false, 2); }
+    else { if (wm == 4) GO(bf16, false, 4); else if (wm == 1) GO(bf16, false, 1); else GO(bf16, false, 2); }
   }
 #undef GO
   return -1;

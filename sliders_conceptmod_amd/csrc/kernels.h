@@ -38,6 +38,12 @@ struct GemmParams {
   int lora_seg = 0;
   float lora_scale = 0.f;
   int lora_row0 = 0;  // rows m < lora_row0 get no delta (frozen samples of a batched pass); xa row = m - lora_row0
+  // fused GEGLU (diffusers GEGLU: proj(x).chunk(2) -> hidden * gelu(gate)), dense v2 kernel only: N = 2 * N_half,
+  // every 128-column tile holds 64 hidden + their 64 gate columns; geglu_out [M, N/2] receives hidden * gelu(gate)
+  // computed from the 16-bit-rounded projection (bit-identical to projection + separate GEGLU kernel); the projection
+  // itself is stored to C only for rows m >= geglu_row0 (the rows whose backward needs it).  bias only.
+  void* geglu_out = nullptr;
+  int geglu_row0 = 0;
   // implicit-GEMM 3x3 convolution (pad 1)
   int conv = 0;
   int Nb = 0, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0;
@@ -46,6 +52,7 @@ struct GemmParams {
   int transposed = 0;  // gradient of a strided conv: out = (in + 1 - k) / stride
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
+bool gemm_geglu_supported(const GemmParams& p);  // can launch_gemm take p.geglu_out?
 
 // direct 3x3 conv for tiny channel counts (conv_in: Cin=4; conv_out: Cout=4 and their gradients)
 // in [Nb,H,W,Cin] T ; w f32-free: T [Cout][9*Cin] ; out [Nb,H,W,Cout] (T or f32), stride 1 pad 1
