@@ -109,7 +109,45 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
     w_ptr[j] = (n < p.N) ? Wp + (int64_t)n * p.K : nullptr;
   }
 
+  // dense operands with K % 64 == 0 (every layer of the UNets): the source of each LDS-DMA is a per-lane pointer that
+  // simply advances by 64 elements per K-step (rows that do not exist keep pointing at the zero page with step 0):
+  // 2 VALU per load instead of ~10 -- the K loop was issuing 3.9 VALU per MFMA, more than the MFMA leaves issue
+  // slots for
+  const bool inc_path = !CONV && (p.K % BK) == 0;
+  const T* a_src[A_INSTR];
+  const T* w_src[B_INSTR];
+  int a_step[A_INSTR], w_step[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const bool ok = !CONV && a_ptr[j] != nullptr;
+    a_src[j] = ok ? a_ptr[j] + a_chunk[j] * 8 : reinterpret_cast<const T*>(zero);
+    a_step[j] = ok ? BK : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    const bool ok = w_ptr[j] != nullptr;
+    w_src[j] = ok ? w_ptr[j] + w_chunk[j] * 8 : reinterpret_cast<const T*>(zero);
+    w_step[j] = ok ? BK : 0;
+  }
+  auto stage_inc = [&](int buf) {
+    unsigned char* As = smem + buf * STAGE;
+    unsigned char* Bs = As + BM * BK * 2;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      glds16(a_src[j], As + (wave * A_INSTR + j) * 1024);
+      a_src[j] += a_step[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      glds16(w_src[j], Bs + (wave * B_INSTR + j) * 1024);
+      w_src[j] += w_step[j];
+    }
+  };
   auto stage = [&](int kt, int buf) {
+    if (inc_path) {
+      stage_inc(buf);
+      return;
+    }
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + BM * BK * 2;
     const int k0 = kt * BK;
@@ -178,28 +216,38 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   const int fr = lane & 15;
   const int fq = lane >> 4;
 
+  // per-lane LDS byte offsets of the 2 x (4 + 4) fragments of a stage, computed once
+  int offA[2][4], offB[2][4];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = kk * 4 + fq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rm = wm * 64 + i * 16 + fr;
+      offA[kk][i] = rm * 128 + ((ch ^ (rm & 7)) << 4);
+      const int rn = wn * 64 + i * 16 + fr;
+      offB[kk][i] = BM * BK * 2 + rn * 128 + ((ch ^ (rn & 7)) << 4);
+    }
+  }
+
   stage(0, 0);
   __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
     const unsigned char* As = smem + buf * STAGE;
-    const unsigned char* Bs = As + BM * BK * 2;
     // fragments of both 32-deep halves are fetched up front (two register sets) so the second half's LDS latency
     // hides under the first half's MFMAs
     typename TT<T>::v8 xa[2][4], wb[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int ch = kk * 4 + fq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int rm = wm * 64 + i * 16 + fr;
         Pack8<T> t;
-        t.u = *reinterpret_cast<const u32x4*>(As + rm * 128 + ((ch ^ (rm & 7)) << 4));
+        t.u = *reinterpret_cast<const u32x4*>(As + offA[kk][i]);
         xa[kk][i] = t.v;
-        const int rn = wn * 64 + i * 16 + fr;
         Pack8<T> s;
-        s.u = *reinterpret_cast<const u32x4*>(Bs + rn * 128 + ((ch ^ (rn & 7)) << 4));
+        s.u = *reinterpret_cast<const u32x4*>(As + offB[kk][i]);
         wb[kk][i] = s.v;
       }
     }
