@@ -1,0 +1,147 @@
+"""Image-slider trainer (reference: trainscripts/imagesliders/train_lora-scale-xl.py:42-548, SD-1.x twin
+train_lora-scale.py) -- the two-sided step on the HIP engine.
+
+Per step (I/train_lora-scale-xl.py:178-401): pick |scale| s, a paired (low, high) latent, one seed for both noises;
+noisy latents = scheduler.add_noise(latent, noise, t) (I/train_util.py:200-235); then
+    set_lora_slider(+s): eps = predict_noise_xl(high_noised, positive prompt) -> MSE(eps, high_noise) -> backward()
+    set_lora_slider(-s): eps = predict_noise_xl(low_noised,  neutral  prompt) -> MSE(eps, low_noise)  -> backward()
+gradients accumulate, one optimizer.step().  (The reference also runs two frozen passes whose results the loss never
+uses, :263-308; they are skipped here -- they cannot change the result.)
+
+Scope note: the reference encodes the image pair with the VAE every step.  The VAE (and the CLIP front end) is a
+"next" row of this tier, so this trainer consumes PRE-ENCODED latents: `--folder_main` holds, per scale folder given in
+`--folders` (e.g. "bigsize,smallsize") a `<name>.pt` / `.safetensors` tensor [4, h, w] per image (already multiplied by
+the VAE scaling factor).  Everything downstream of the encode is the reference's arithmetic."""
+import argparse
+import os
+import random
+from pathlib import Path
+
+import torch
+from tqdm import tqdm
+
+from . import config_util, model_util, parallel, prompt_util, train_util
+from .lora import LoRANetwork
+from .train_lora_xl import encode_xl
+
+
+def image_slider_step(unet, network, scheduler, lat_low, lat_high, noise_low, noise_high, timestep, pos, neu,
+                      add_time_ids, scale: float, guidance_scale: float = 1.0):
+    """The two adapted passes + two backward()s of one image-slider step; returns (loss_high, loss_low)."""
+    bs = lat_high.shape[0]
+
+    def cond(e):
+        # the image sliders pair each prompt with itself in the CFG batch (I/train_lora-scale-xl.py:321-329)
+        return dict(text_embeddings=train_util.concat_embeddings(e.text_embeds, e.text_embeds, bs),
+                    add_text_embeddings=train_util.concat_embeddings(e.pooled_embeds, e.pooled_embeds, bs),
+                    add_time_ids=train_util.concat_embeddings(add_time_ids, add_time_ids, bs))
+
+    losses = []
+    for sgn, lat, noise, emb in ((+1.0, lat_high, noise_high, pos), (-1.0, lat_low, noise_low, neu)):
+        network.set_lora_slider(scale=sgn * scale)
+        with network:
+            pred = train_util.predict_noise_xl(unet, scheduler, timestep, lat, **cond(emb),
+                                               guidance_scale=guidance_scale)
+        loss = torch.nn.functional.mse_loss(pred.float(), noise.float())  # fp32 at the loss, I/..-xl.py:282,338
+        loss.backward()  # gradients of the two sides accumulate (I/train_lora-scale-xl.py:345,377)
+        losses.append(loss.detach())
+    network.set_lora_slider(scale=1)
+    return losses[0], losses[1]
+
+
+def _load_latent(path):
+    if str(path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return next(iter(load_file(str(path)).values()))
+    return torch.load(path, weights_only=True)
+
+
+def train(config, prompts, device, folder_main, folders, scales, models=None, rank=4):
+    weight_dtype = config_util.parse_precision(config.train.precision)
+    tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
+        config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=True)
+    unet.to(device, dtype=weight_dtype)
+    unet.requires_grad_(False)
+    unet.eval()
+    network = LoRANetwork(unet, rank=rank, multiplier=1.0, alpha=config.network.alpha,
+                          train_method=config.network.training_method).to(device, dtype=weight_dtype)
+    optimizer = train_util.get_optimizer(config.train.optimizer)(network.prepare_optimizer_params(),
+                                                                 lr=config.train.lr)
+    lr_scheduler = train_util.get_lr_scheduler(config.train.lr_scheduler, optimizer,
+                                               max_iterations=config.train.iterations, lr_min=config.train.lr / 100)
+    settings = prompts[0]
+    with torch.no_grad():
+        pos = encode_xl(text_encoders, tokenizers, settings.positive, device, weight_dtype)
+        neu = encode_xl(text_encoders, tokenizers, settings.neutral, device, weight_dtype)
+    scales = sorted(float(s) for s in scales)
+    folders = [f for _, f in sorted(zip([float(s) for s in scales], folders))] if len(folders) == len(scales) else folders
+    names = sorted(os.listdir(os.path.join(folder_main, folders[0])))
+    rank_, world = parallel.world_info()
+    save_path = Path(config.save.path)
+    for i in tqdm(range(config.train.iterations), disable=rank_ != 0):
+        noise_scheduler.set_timesteps(config.train.max_denoising_steps, device=device)
+        optimizer.zero_grad()
+        timesteps_to = torch.randint(1, config.train.max_denoising_steps - 1, (1,)).item()
+        scale_to_look = abs(random.choice(scales))
+        f_low = folders[scales.index(-scale_to_look)]
+        f_high = folders[scales.index(scale_to_look)]
+        name = names[(random.randint(0, len(names) - 1) + rank_) % len(names)]  # ranks take different pairs
+        lat_low = _load_latent(os.path.join(folder_main, f_low, name)).unsqueeze(0).float()
+        lat_high = _load_latent(os.path.join(folder_main, f_high, name)).unsqueeze(0).float()
+        seed = random.randint(0, 2 * 15)
+        t = noise_scheduler.timesteps[timesteps_to]
+        g = torch.Generator().manual_seed(seed)
+        noise_low = torch.randn(lat_low.shape, generator=g)
+        g = torch.Generator().manual_seed(seed)
+        noise_high = torch.randn(lat_high.shape, generator=g)
+        nl = noise_scheduler.add_noise(lat_low, noise_low, t).to(device)
+        nh = noise_scheduler.add_noise(lat_high, noise_high, t).to(device)
+        h, w = lat_low.shape[-2] * 8, lat_low.shape[-1] * 8
+        tid = train_util.get_add_time_ids(h, w, dtype=torch.float32).to(device)
+        noise_scheduler.set_timesteps(1000)
+        cur_t = noise_scheduler.timesteps[int(timesteps_to * 1000 / config.train.max_denoising_steps)]
+        image_slider_step(unet, network, noise_scheduler, nl, nh, noise_low.to(device), noise_high.to(device), cur_t,
+                          pos, neu, tid, scale_to_look)
+        parallel.allreduce_mean_(network.flat.grad)
+        optimizer.step()
+        lr_scheduler.step()
+    if rank_ == 0:
+        save_path.mkdir(parents=True, exist_ok=True)
+        network.save_weights(save_path / f"{config.save.name}_last.safetensors",
+                             dtype=config_util.parse_precision(config.train.precision))
+    return network
+
+
+def main(args):
+    config = config_util.load_config_from_yaml(args.config_file)
+    if args.name is not None:
+        config.save.name = args.name
+    attributes = [a.strip() for a in args.attributes.split(",")] if args.attributes is not None else []
+    config.network.alpha = args.alpha
+    config.network.rank = args.rank
+    config.save.name += f"_alpha{args.alpha}_rank{config.network.rank}_{config.network.training_method}"
+    config.save.path += f"/{config.save.name}"
+    prompts = prompt_util.load_prompts_from_yaml(config.prompts_file, attributes)
+    device = torch.device(f"cuda:{args.device}")
+    folders = [f.strip() for f in args.folders.split(",")]
+    scales = [float(s.strip()) for s in args.scales.split(",")]
+    train(config, prompts, device, args.folder_main, folders, scales, rank=args.rank)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--config_file", required=False, default="data/config-xl.yaml")
+    p.add_argument("--alpha", type=float, required=True)
+    p.add_argument("--rank", type=int, default=4)
+    p.add_argument("--device", default=0)
+    p.add_argument("--name", type=str, default=None)
+    p.add_argument("--attributes", type=str, default=None)
+    p.add_argument("--folder_main", type=str, required=True, help="directory holding one sub-folder per scale")
+    p.add_argument("--stylecheck", type=str, default=None)
+    p.add_argument("--folders", type=str, default="verylow, low, high, veryhigh")
+    p.add_argument("--scales", type=str, default="-2, -1, 1, 2")
+    return p
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

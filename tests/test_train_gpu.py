@@ -108,3 +108,60 @@ def test_fused_step_matches_autograd_step(goldens, tmp_path):
     a, b = res
     rel = float((a - b).norm() / b.norm())
     assert rel < 2e-3, f"fused vs autograd parameter distance {rel:.2e}"
+
+
+def test_image_slider_two_sided_step_matches_oracle(goldens):
+    """Row a-10: slider at +s on the 'high' latent and -s on the 'low' latent, two backward()s accumulate; against the
+    oracle's autograd on the same inputs (LoRA multiplier = +/- s, MSE to the true noise)."""
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.model_util as MU
+    import sliders_conceptmod_amd.unet as PU
+    from sliders_conceptmod_amd.prompt_util import PromptEmbedsXL
+    from sliders_conceptmod_amd.train_lora_scale_xl import image_slider_step
+    from oracle import sched_ref as S, slider_ref as R
+    ocfg = CFGS["tiny_sdxl"]()
+    ou = OU.init_synthetic_(OU.UNet2DConditionModel(ocfg), seed=0).requires_grad_(False).eval()
+    pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(ocfg)))
+    pu.load_state_dict(ou.state_dict())
+    pu = pu.to("cuda", torch.float16).requires_grad_(False).eval()
+    torch.manual_seed(1)
+    onet = R.LoRANetworkRef(ou, 4, 1.0, 1.0, "noxattn")
+    torch.manual_seed(1)
+    pnet = L.LoRANetwork(pu, rank=4, alpha=1.0, train_method="noxattn")
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+            w = torch.randn(lo.lora_up.weight.shape, generator=g) * 0.05
+            lo.lora_up.weight.copy_(w)
+            lp.lora_up.weight.copy_(w)
+    pnet.to("cuda")
+    g = torch.Generator().manual_seed(5)
+    emb = {k: (torch.randn(1, 77, 64, generator=g), torch.randn(1, 64, generator=g)) for k in ("pos", "neu")}
+    lat = {k: torch.randn(1, 4, 16, 16, generator=g) for k in ("low", "high")}
+    noise = torch.randn(1, 4, 16, 16, generator=g)
+    tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]])
+    osch, psch = S.create_noise_scheduler_ref("ddim"), MU.create_noise_scheduler("ddim")
+    osch.set_timesteps(1000), psch.set_timesteps(1000)
+    t = psch.timesteps[600]
+    scale = 2.0
+    # oracle: same arithmetic with autograd
+    for sgn, key, ek in ((+1.0, "high", "pos"), (-1.0, "low", "neu")):
+        onet.set_lora_slider(sgn * scale)
+        x = osch.add_noise(lat[key], noise, torch.tensor([int(t)]))
+        te, pe = emb[ek]
+        with onet:
+            pred = R.predict_noise_xl(ou, osch, osch.timesteps[600], x, torch.cat([te, te]), torch.cat([pe, pe]),
+                                      torch.cat([tid, tid]), guidance_scale=1.0)
+        torch.nn.functional.mse_loss(pred, noise).backward()
+    nl = psch.add_noise(lat["low"], noise, t).cuda()
+    nh = psch.add_noise(lat["high"], noise, t).cuda()
+    pos = PromptEmbedsXL(emb["pos"][0].cuda().half(), emb["pos"][1].cuda().half())
+    neu = PromptEmbedsXL(emb["neu"][0].cuda().half(), emb["neu"][1].cuda().half())
+    image_slider_step(pu, pnet, psch, nl, nh, noise.cuda(), noise.cuda(), t, pos, neu, tid.cuda(), scale)
+    num = den = 0.0
+    for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+        for a, b in ((lp.lora_down.grad, lo.lora_down.weight.grad), (lp.lora_up.grad, lo.lora_up.weight.grad)):
+            num += float((a.cpu() - b).norm() ** 2)
+            den += float(b.norm() ** 2)
+    rel = (num / den) ** 0.5
+    assert rel < 1e-2, f"two-sided image-slider LoRA gradient vs oracle: {rel:.2e}"
