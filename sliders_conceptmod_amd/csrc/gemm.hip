@@ -293,16 +293,23 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const T* __restrict_
 bool gemm2_supported(const GemmParams& p);
 bool gemm2_geglu_supported(const GemmParams& p);
 int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream);
+bool gemm3_supported(const GemmParams& p);
+int launch_gemm3(const GemmParams& p, hipStream_t stream);
 
 // SMI_GEMM=v1 forces the register-staged kernel, SMI_GEMM=128 / 256 forces a v2 tile height (A/B experiments)
 static int gemm_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SMI_GEMM");
-    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : 0)))));
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : 0)))))));
   }
   return mode;
 }
+
+// shapes where the 256x256 tile is the better choice (measured, tools/bench_gemm.py)
+// (one 256x256 workgroup per CU: it needs >= 2 full rounds of tiles to amortise its longer fill / epilogue; below that
+// the 128-row v2 tiles with 2-3 resident workgroups per CU win)
+static bool gemm3_wanted(const GemmParams& p) { return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 512; }
 
 bool gemm_geglu_supported(const GemmParams& p) { return gemm_mode() != 3 && gemm2_geglu_supported(p); }
 
@@ -310,12 +317,14 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   SMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   SMI_CHECK(!p.geglu_out || gemm_geglu_supported(p), "gemm: fused GEGLU not available for this shape/layout");
   // v2 (LDS-DMA staging, full-row epilogue) serves dense GEMMs and convs; SMI_GEMM=convv1 keeps convs on v1, =v1 all
+  // v3 (256x256 tile, 8-phase schedule): SMI_GEMM=8ph forces it wherever its layout rules hold, =no8ph disables it
+  if ((gemm_mode() == 6 || (gemm_mode() == 0 && gemm3_wanted(p))) && gemm3_supported(p)) return launch_gemm3(p, stream);
   if (gemm_mode() != 3 && gemm2_supported(p) && (!p.conv || gemm_mode() != 4)) {
     if (p.conv) {
       SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
                 "conv: inconsistent geometry");
     }
-    return launch_gemm2(p, gemm_mode() == 4 ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode()), stream);
+    return launch_gemm2(p, (gemm_mode() == 4 || gemm_mode() >= 6) ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode()), stream);
   }
   SMI_CHECK(p.K % 8 == 0 && p.N % 4 == 0, "gemm: K %% 8 and N %% 4 must be 0 (K=%d N=%d)", p.K, p.N);
   SMI_CHECK(p.ldc % 4 == 0, "gemm: ldc %% 4 != 0");

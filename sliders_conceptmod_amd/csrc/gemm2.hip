@@ -53,8 +53,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int bm0 = (wg / nbn) * BM;
-  const int bn0 = (wg % nbn) * BN;
+  // grouped rasterisation: consecutive workgroups (= the ones co-resident on one XCD after the remap above) sweep a
+  // band of GW column tiles before moving down a row tile, so the 32-64 tiles sharing an L2 form a ~8x8 patch
+  // (8 + 8 operand panels per K-step instead of 1 + 64 for a wide-N GEMM walked row-major)
+  constexpr int GW = 8;
+  const int nbm = (p.M + BM - 1) / BM;
+  const int grp = wg / (GW * nbm);
+  const int gw = min(nbn - grp * GW, GW);
+  const int lw = wg - grp * GW * nbm;
+  const int bm0 = (lw / gw) * BM;
+  const int bn0 = (grp * GW + lw % gw) * BN;
   const bool geglu = p.geglu_out != nullptr;
   const int nhalf = p.N >> 1;
   // tile-local column nl (0..127) -> global output column

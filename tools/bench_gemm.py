@@ -47,11 +47,12 @@ def conv(nb, H, Cin, Cout, dt=torch.float16):
 if __name__ == "__main__":
     gemm(4096, 4096, 4096)
     gemm(8192, 8192, 8192)
-    for M, N, K in [(16384, 1920, 640), (16384, 640, 640), (16384, 5120, 640), (16384, 640, 2560),
-                    (4096, 3840, 1280), (4096, 1280, 1280), (4096, 10240, 1280), (4096, 1280, 5120),
-                    (308, 1280, 2048), (308, 2560, 2048)]:
+    # batched 4-pass step, SD-XL 1024^2 B=2: 16 samples -> 65536 rows at 640 channels, 16384 rows at 1280
+    for M, N, K in [(65536, 1920, 640), (65536, 640, 640), (65536, 5120, 640), (65536, 640, 2560),
+                    (16384, 3840, 1280), (16384, 1280, 1280), (16384, 10240, 1280), (16384, 1280, 5120),
+                    (4096, 1280, 1280), (4096, 1280, 5120), (1232, 2560, 2048)]:
         gemm(M, N, K)
         gemm(M, N, K, epi=True)
-    for nb, H, Cin, Cout in [(4, 128, 320, 320), (4, 64, 640, 640), (4, 32, 1280, 1280), (4, 64, 1920, 640),
-                             (4, 128, 960, 320), (4, 32, 2560, 1280)]:
+    for nb, H, Cin, Cout in [(16, 128, 320, 320), (16, 64, 640, 640), (16, 32, 1280, 1280), (16, 64, 1920, 640),
+                             (16, 128, 960, 320), (16, 32, 2560, 1280)]:
         conv(nb, H, Cin, Cout)
