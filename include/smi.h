@@ -173,6 +173,12 @@ int smi_op_groupnorm(int dtype, const void* x, const void* gamma, const void* be
 int smi_op_layernorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
                      float* mean_rstd, int m, int c, float eps, void* stream);
 int smi_op_geglu(int dtype, const void* proj, void* out, const void* dout, void* dproj, int m, int c4, void* stream);
+/* ff.net.0 with the GEGLU gate fused into the GEMM epilogue (the engine's forward path for
+ * diffusers GEGLU: proj = x W^T + b [M, N]; out[M, N/2] = proj[:, :N/2] * gelu(proj[:, N/2:])).  Rows >= proj_row0 of
+ * proj are also written (row m at proj + m*N); pass proj_row0 = M to keep none.  Fails when the layout is not
+ * supported by the fused kernel (N % 256 != 0, misaligned operands). */
+int smi_op_gemm_geglu(int dtype, const void* A, const void* W, const void* bias, void* out, void* proj, int M, int N,
+                      int K, int proj_row0, void* stream);
 int smi_op_lora_down(int dtype, const void* x, const float* a, float* xa, int m, int k, int r, void* stream);
 int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m, int k, int r, float alpha,
                       float* scratch, void* stream);

@@ -1589,6 +1589,23 @@ int smi_op_gemm(int dtype, const void* A, const void* W, void* C, int M, int N, 
   p.lora_scale = lora_scale;
   return launch_gemm(p, (hipStream_t)stream);
 }
+int smi_op_gemm_geglu(int dtype, const void* A, const void* W, const void* bias, void* out, void* proj, int M, int N,
+                      int K, int proj_row0, void* stream) {
+  GemmParams p;
+  p.dtype = dtype;
+  p.A = A;
+  p.lda = K;
+  p.W = W;
+  p.C = proj;
+  p.ldc = N;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.bias = bias;
+  p.geglu_out = out;
+  p.geglu_row0 = proj_row0;
+  return launch_gemm(p, (hipStream_t)stream);
+}
 int smi_op_conv3x3(int dtype, const void* in, const void* w_packed, const void* bias, void* out, int nb, int hin,
                    int win, int cin, int cout, int stride, int upsample, int transposed, int hout, int wout,
                    void* stream) {

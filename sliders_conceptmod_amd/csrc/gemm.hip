@@ -309,7 +309,11 @@ static int gemm_mode() {
 // shapes where the 256x256 tile is the better choice (measured, tools/bench_gemm.py)
 // (one 256x256 workgroup per CU: it needs >= 2 full rounds of tiles to amortise its longer fill / epilogue; below that
 // the 128-row v2 tiles with 2-3 resident workgroups per CU win)
-static bool gemm3_wanted(const GemmParams& p) { return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 512; }
+// convs: only where Cout fills whole 256-column tiles (320 / 640 output channels lose 17-38 % of a tile row)
+static bool gemm3_wanted(const GemmParams& p) {
+  if (p.conv && p.N % 256 != 0) return false;
+  return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 512;
+}
 
 bool gemm_geglu_supported(const GemmParams& p) { return gemm_mode() != 3 && gemm2_geglu_supported(p); }
 

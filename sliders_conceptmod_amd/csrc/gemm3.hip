@@ -22,6 +22,8 @@
 //
 // Rows beyond M / N are clamped to the last valid row (their results are never stored), so the source of every DMA is
 // a per-lane pointer that just advances 128 bytes per K-tile.  Requires K % 64 == 0 (all UNet layers); others use v2.
+// CONV = implicit-GEMM 3x3 / stride 1 / pad 1: K runs over (tap, channel); an A row is a pixel, its source for a K-tile
+// is the centre-tap pointer + a wave-uniform tap offset, or a zero page when the tap falls outside the image.
 #include "kernels.h"
 
 #include <type_traits>
@@ -44,7 +46,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 #define SMI_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <typename T>
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page3[256];  // zero-initialised (conv padding source)
+
+template <typename T, bool CONV>
 __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
   typedef typename TT<T>::v8 v8;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
   // ---- LDS-DMA sources.  Half-tile instruction j of wave w covers LDS rows r = 16 w + 8 j + (lane >> 3); the lane's
   //      16-byte slot (lane & 7) holds source chunk slot ^ (r & 7)  (the read side applies the same XOR).
   const int lrow = lane >> 3, lslot = lane & 7;
-  const T* aS[2][2];
+  const T* aS[2][2];   // dense: running source pointer; conv: centre-tap pointer of the row's pixel
+  int amask[2][2];     // conv: bit (3 ky + kx) set when that tap of the row's pixel lies inside the image
   const T* wS[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -87,20 +92,60 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
       const int r = wave * 16 + j * 8 + lrow;
       const int chunk = lslot ^ lrow;
       // A-h{h}: LDS row r = 64 wr' + local  <-  tile row 128 wr' + 64 h + local
-      const int m = min(bm0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
-      aS[h][j] = reinterpret_cast<const T*>(p.A) + (int64_t)m * p.lda + chunk * 8;
+      const int mrow = bm0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      if (CONV) {  // 3x3, stride 1, pad 1 (the other gather modes stay on gemm2.hip): Hout == Hin, Wout == Win
+        const int m = min(mrow, p.M - 1);
+        const int hw = p.Hin * p.Win;
+        const int img = m / hw;
+        const int rem = m - img * hw;
+        const int oy = rem / p.Win, ox = rem - oy * p.Win;
+        int mk = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const bool ok = (unsigned)(oy + ky - 1) < (unsigned)p.Hin && (unsigned)(ox + kx - 1) < (unsigned)p.Win;
+            mk |= ok ? (1 << (3 * ky + kx)) : 0;
+          }
+        amask[h][j] = mrow < p.M ? mk : 0;
+        aS[h][j] = reinterpret_cast<const T*>(p.A) + (int64_t)m * p.Cin + chunk * 8;
+      } else {
+        const int m = min(mrow, p.M - 1);
+        amask[h][j] = 0;
+        aS[h][j] = reinterpret_cast<const T*>(p.A) + (int64_t)m * p.lda + chunk * 8;
+      }
       // B-h{h}: LDS row r = 32 wc' + 16 nip + fr  <-  W row (output column) 64 wc' + 32 h + 8 (fr >> 2) + 4 nip + (fr & 3):
       // after the two MFMAs of a pair a lane owns 8 consecutive output columns (16-byte epilogue accesses)
       const int fr_ = r & 15, nip = (r >> 4) & 1;
       const int n = min(gcol((r >> 5) * 64 + 32 * h + 8 * (fr_ >> 2) + 4 * nip + (fr_ & 3)), p.N - 1);
       wS[h][j] = reinterpret_cast<const T*>(p.W) + (int64_t)n * p.K + chunk * 8;
     }
+  // conv: K position of the next A half-tile to stage, per half (wave-uniform): channel offset and tap
+  int cA[2] = {0, 0}, kyA[2] = {0, 0}, kxA[2] = {0, 0};
   // dst: half-tile base + (2 wave + j) KiB
   auto stage_a = [&](int h, unsigned char* dst) {
+    if (CONV) {
+      const int toff = ((kyA[h] - 1) * p.Win + (kxA[h] - 1)) * p.Cin + cA[h];
+      const int tap = kyA[h] * 3 + kxA[h];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      glds16(aS[h][j], dst + (wave * 2 + j) * 1024);
-      aS[h][j] += BK;
+      for (int j = 0; j < 2; ++j) {
+        const void* src = ((amask[h][j] >> tap) & 1) ? (const void*)(aS[h][j] + toff) : (const void*)g_zero_page3;
+        glds16(src, dst + (wave * 2 + j) * 1024);
+      }
+      cA[h] += BK;
+      if (cA[h] == p.Cin) {
+        cA[h] = 0;
+        if (++kxA[h] == 3) {
+          kxA[h] = 0;
+          ++kyA[h];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        glds16(aS[h][j], dst + (wave * 2 + j) * 1024);
+        aS[h][j] += BK;
+      }
     }
   };
   auto stage_w = [&](int h, unsigned char* dst) {
@@ -370,15 +415,16 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
   }
 }
 
-template <typename T>
+template <typename T, bool CONV>
 int launch_t(const GemmParams& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_8ph_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3));
+    SMI_HIP(hipFuncSetAttribute((const void*)gemm_8ph_kernel<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SMEM3));
     attr_done = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_8ph_kernel<T>), dim3(grid), dim3(512), SMEM3, stream, p);
+  hipLaunchKernelGGL((gemm_8ph_kernel<T, CONV>), dim3(grid), dim3(512), SMEM3, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -389,7 +435,10 @@ bool gemm2_supported(const GemmParams& p);
 
 // dense GEMMs whose layout the 8-phase kernel takes: everything gemm2 takes, plus K % 64 == 0 and N % 8 == 0
 bool gemm3_supported(const GemmParams& p) {
-  if (p.conv || !gemm2_supported(p)) return false;
+  if (!gemm2_supported(p)) return false;
+  if (p.conv && (p.stride != 1 || p.upsample || p.transposed || p.Cin % BK != 0 || p.Hout != p.Hin || p.Wout != p.Win ||
+                 p.K != 9 * p.Cin || p.M != p.Nb * p.Hout * p.Wout))
+    return false;
   if (p.K % BK != 0 || p.N % 8 != 0 || p.lora_seg % 8 != 0) return false;
   if (p.out_f32 && p.ldc % 4 != 0) return false;
   if (p.geglu_out && p.N % 512 != 0) return false;
@@ -397,8 +446,8 @@ bool gemm3_supported(const GemmParams& p) {
 }
 
 int launch_gemm3(const GemmParams& p, hipStream_t stream) {
-  if (p.dtype == DT_F16) return launch_t<f16>(p, stream);
-  return launch_t<bf16>(p, stream);
+  if (p.dtype == DT_F16) return p.conv ? launch_t<f16, true>(p, stream) : launch_t<f16, false>(p, stream);
+  return p.conv ? launch_t<bf16, true>(p, stream) : launch_t<bf16, false>(p, stream);
 }
 
 }  // namespace smi

@@ -89,6 +89,47 @@ def test_gemm_full_epilogue(lib, dt, r):
     torch.testing.assert_close(c32, a.float() @ w.float().t() + bias.float(), rtol=2e-5, atol=2e-4)
 
 
+# ---- shapes with >= 512 tiles of 256 x 256 run on the 8-phase kernel (gemm3.hip); the smaller ones above on gemm2.hip
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(8192, 4096, 64), (8192, 4096, 192), (8200, 4104, 320), (16384, 2048, 1280)])
+def test_gemm_8phase_tile_epilogues_and_tails(lib, dt, M, N, K):
+    a, w = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    bias, res = rnd(N, dt=dt, seed=3), rnd(M, N, dt=dt, seed=4)
+    r, s = 4, 0.375
+    xa = torch.randn(M, r, device="cuda")
+    up = torch.randn(N, r, device="cuda") * 0.1
+    c = torch.empty(M, N, device="cuda", dtype=dt)
+    chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c), M, N, K, None, None, None, None, 0, 0.0, 0, None))
+    base = a.float() @ w.float().t()
+    close(c, base, dt, what="gemm")
+    chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up), r, s, 0, None))
+    close(c, base + bias.float() + res.float() + s * (xa @ up.t()), dt, what="gemm+bias+res+lora")
+    c32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c32), M, N, K, P(bias), None, None, None, 0, 0.0, 1, None))
+    torch.testing.assert_close(c32, base + bias.float(), rtol=2e-5, atol=2e-4)
+    # the staggered-wave / counted-vmcnt schedule must be deterministic: identical bits run after run
+    c2 = torch.empty_like(c)
+    for _ in range(5):
+        chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c2), M, N, K, P(bias), P(res), P(xa), P(up), r, s, 0, None))
+        assert torch.equal(c, c2)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(520, 1024, 320), (4096, 5120, 640), (16384, 10240, 320), (8200, 5120, 128)])
+def test_gemm_fused_geglu_epilogue(lib, dt, M, N, K):
+    """Both tile sizes (128-row v2 below 512 big tiles, 256x256 8-phase above) against proj -> hidden * gelu(gate)."""
+    a, w, bias = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2), rnd(N, dt=dt, seed=3)
+    row0 = (M // 3) & ~7
+    out = torch.empty(M, N // 2, device="cuda", dtype=dt)
+    proj = torch.full((M, N), 7.0, device="cuda", dtype=dt)
+    chk(lib, lib.smi_op_gemm_geglu(dcode(dt), P(a), P(w), P(bias), P(out), P(proj), M, N, K, row0, None))
+    pref = a.float() @ w.float().t() + bias.float()
+    close(proj[row0:], pref[row0:], dt, what="geglu: kept projection rows")
+    assert bool((proj[:row0] == 7.0).all()), "projection rows below proj_row0 must not be written"
+    pq = pref.to(dt).float()  # the gate is applied to the 16-bit-rounded projection, as the unfused path does
+    close(out, pq[:, :N // 2] * F.gelu(pq[:, N // 2:]), dt, what="geglu out")
+
+
 def pack_fwd(w):  # [Cout, Cin, 3, 3] -> [Cout, 9*Cin] in (ky, kx, ci) order
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
@@ -99,7 +140,8 @@ def pack_grad(w, flip):  # -> [Cin, 9*Cout], taps flipped for stride-1 gradients
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("nb,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320)])
+@pytest.mark.parametrize("nb,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 12, 20, 128, 64), (3, 8, 8, 320, 320),
+                                             (9, 60, 62, 64, 1024)])  # last: >= 512 tiles of 256x256 -> gemm3.hip
 def test_conv3x3_forward_and_input_gradient(lib, dt, nb, H, W, Cin, Cout):
     x = rnd(nb, H, W, Cin, dt=dt, seed=1)  # NHWC
     w = rnd(Cout, Cin, 3, 3, dt=dt, scale=(9 * Cin) ** -0.5, seed=2)

@@ -37,5 +37,31 @@ for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
                 print(f"   run {rep}: {nd} elements differ from the first run -> RACE", flush=True)
                 bad += 1
                 break
+# implicit-GEMM 3x3 convs (NHWC activations, [Cout, 9 Cin] tap-major filters), incl. ragged M and image borders
+for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
+    for (nb, H, W, Cin, Cout) in [(16, 64, 64, 64, 256), (3, 40, 56, 128, 520), (16, 128, 128, 320, 320),
+                                  (16, 32, 32, 1280, 1280), (5, 33, 47, 192, 1024)]:
+        x = torch.randn(nb, H, W, Cin, device="cuda").to(dt)
+        w = (torch.randn(Cout, 9 * Cin, device="cuda") * (9 * Cin) ** -0.5).to(dt)
+        b = torch.randn(Cout, device="cuda").to(dt)
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2),
+                                         w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b.float(),
+                                         padding=1).permute(0, 2, 3, 1)
+        first = None
+        for rep in range(10):
+            y = torch.empty(nb, H, W, Cout, device="cuda", dtype=dt)
+            rc = lib.smi_op_conv3x3(code, P(x), P(w), P(b), P(y), nb, H, W, Cin, Cout, 1, 0, 0, H, W, None)
+            assert rc == 0
+            torch.cuda.synchronize()
+            if first is None:
+                first = y.clone()
+                err = float((y.float() - ref).abs().max() / ref.abs().max())
+                ok = err < (2e-3 if dt == torch.float16 else 1.2e-2)
+                print(f"{str(dt):15s} conv nb={nb} {H}x{W} {Cin}->{Cout}: rel err {err:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+                bad += 0 if ok else 1
+            elif not torch.equal(y, first):
+                print(f"   run {rep}: differs from the first run -> RACE", flush=True)
+                bad += 1
+                break
 print("FAILED" if bad else "ALL OK")
 sys.exit(1 if bad else 0)
