@@ -301,7 +301,7 @@ static int gemm_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SMI_GEMM");
-    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : 0)))))));
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : 0))))))));
   }
   return mode;
 }
@@ -312,7 +312,7 @@ static int gemm_mode() {
 // convs: only where Cout fills whole 256-column tiles (320 / 640 output channels lose 17-38 % of a tile row)
 static bool gemm3_wanted(const GemmParams& p) {
   if (p.conv && p.N % 256 != 0) return false;
-  return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 512;
+  return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 512;  // (N = 1280 convs at 16384 rows: 320 tiles -> gemm2 128x160)
 }
 
 bool gemm_geglu_supported(const GemmParams& p) { return gemm_mode() != 3 && gemm2_geglu_supported(p); }
@@ -328,7 +328,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
       SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
                 "conv: inconsistent geometry");
     }
-    return launch_gemm2(p, (gemm_mode() == 4 || gemm_mode() >= 6) ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode()), stream);
+    return launch_gemm2(p, gemm_mode() == 8 ? 4 : ((gemm_mode() == 4 || gemm_mode() >= 6) ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode())), stream);
   }
   SMI_CHECK(p.K % 8 == 0 && p.N % 4 == 0, "gemm: K %% 8 and N %% 4 must be 0 (K=%d N=%d)", p.K, p.N);
   SMI_CHECK(p.ldc % 4 == 0, "gemm: ldc %% 4 != 0");

@@ -22,7 +22,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zer
 
 namespace {
 
-constexpr int BN = 128, BK = 64;
+constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -31,10 +31,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T, bool CONV, int WM>  // WM wave-rows: block tile = (64*WM) x 128, WM*2 waves
+// Block tile = (64 WM) x BN with 2 WM waves.  NL = 0: BN = 128, waves as WM (M) x 2 (N), 64 x 64 per wave.
+// NL = 1: BN = 160, waves as 2 WM (M) x 1 (N), 32 x 160 per wave -- every layer width of the UNets (320 / 640 / 1280 and
+// their multiples) is a multiple of 160 but not of 128 (320 output channels = 2.5 tiles of 128), and N = 1280 splits
+// into 8 column tiles so that e.g. 4096 x 1280 is exactly 256 workgroups, one per CU.
+template <typename T, bool CONV, int WM, int NL>
 __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
+  constexpr int BN = NL ? 160 : 128;
   constexpr int BM = 64 * WM;
   constexpr int NW = WM * 2;
+  constexpr int MI = NL ? 2 : 4;    // 16-row fragments per wave
+  constexpr int NI = NL ? 10 : 4;   // 16-column fragments per wave
+  static_assert(((BN / 8) % NW) == 0, "W tile rows must split evenly over the waves");
   constexpr int STAGE = (BM + BN) * BK * 2;  // bytes
   constexpr int A_INSTR = (BM / 8) / NW;     // 1-KiB wave-instructions per wave for the A tile (= 4)
   constexpr int B_INSTR = (BN / 8) / NW;     // (= 4 or 2)
@@ -43,7 +51,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NL ? wave : wave >> 1, wn = NL ? 0 : wave & 1;
+  constexpr int WROWS = 16 * MI, WCOLS = 16 * NI;  // wave tile
 
   const int nbn = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
@@ -66,7 +75,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   const bool geglu = p.geglu_out != nullptr;
   const int nhalf = p.N >> 1;
   // tile-local column nl (0..127) -> global output column
-  auto gcol = [&](int nl) { return geglu ? (nl < 64 ? (bn0 >> 1) + nl : nhalf + (bn0 >> 1) + nl - 64) : bn0 + nl; };
+  auto gcol = [&](int nl) {
+    return geglu ? (nl < BN / 2 ? (bn0 >> 1) + nl : nhalf + (bn0 >> 1) + nl - BN / 2) : bn0 + nl;
+  };
 
   const unsigned char* zero = g_zero_page;
   const T* Ap = reinterpret_cast<const T*>(p.A);
@@ -109,10 +120,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   for (int j = 0; j < B_INSTR; ++j) {
     const int row = (wave * B_INSTR + j) * 8 + lrow;
     // epilogue lane remap, applied at staging time so fragment reads stay on consecutive (conflict-free) LDS rows:
-    // LDS row 64*wn + 16*ni + fr holds W row 64*wn + 32*(ni>>1) + 8*(fr>>2) + 4*(ni&1) + (fr&3); after the MFMAs
-    // of the pair (2q, 2q+1) a lane then owns the 8 consecutive columns 32q + 8*fq + {0..7}.
-    const int ni_ = (row >> 4) & 3, fr_ = row & 15;
-    const int n = gcol((row & 64) + (ni_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (ni_ & 1) + (fr_ & 3));
+    // LDS row 16*ni + fr (ni counted over the whole tile) holds W row 32*(ni>>1) + 8*(fr>>2) + 4*(ni&1) + (fr&3);
+    // after the MFMAs of the pair (2q, 2q+1) a lane then owns the 8 consecutive columns 32q + 8*fq + {0..7}.
+    const int ni_ = row >> 4, fr_ = row & 15;
+    const int n = gcol((ni_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (ni_ & 1) + (fr_ & 3));
     w_chunk[j] = lslot ^ (row & 7);
     w_ptr[j] = (n < p.N) ? Wp + (int64_t)n * p.K : nullptr;
   }
@@ -214,30 +225,35 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
     }
   };
 
-  f32x4 acc[4][4];  // [ni][mi]
+  f32x4 acc[NI][MI];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
   const int fr = lane & 15;
   const int fq = lane >> 4;
 
   // per-lane LDS byte offsets of the 2 x (4 + 4) fragments of a stage, computed once
-  int offA[2][4], offB[2][4];
+  int offA[2][MI], offB[2][NI];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     const int ch = kk * 4 + fq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rm = wm * 64 + i * 16 + fr;
+    for (int i = 0; i < MI; ++i) {
+      const int rm = wm * WROWS + i * 16 + fr;
       offA[kk][i] = rm * 128 + ((ch ^ (rm & 7)) << 4);
-      const int rn = wn * 64 + i * 16 + fr;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int rn = wn * WCOLS + i * 16 + fr;
       offB[kk][i] = BM * BK * 2 + rn * 128 + ((ch ^ (rn & 7)) << 4);
     }
   }
 
+  // (A 4-stage variant -- three tiles in flight across raw barriers, counted vmcnt, one workgroup per CU -- was built
+  // and measured for the small grids: 4096 x 1280 x 1280 24-36 us against 22.8 us here.  Not kept.)
   stage(0, 0);
   __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
   for (int kt = 0; kt < nk; ++kt) {
@@ -246,14 +262,17 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
     const unsigned char* As = smem + buf * STAGE;
     // fragments of both 32-deep halves are fetched up front (two register sets) so the second half's LDS latency
     // hides under the first half's MFMAs
-    typename TT<T>::v8 xa[2][4], wb[2][4];
+    typename TT<T>::v8 xa[2][MI], wb[2][NI];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         Pack8<T> t;
         t.u = *reinterpret_cast<const u32x4*>(As + offA[kk][i]);
         xa[kk][i] = t.v;
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
         Pack8<T> s;
         s.u = *reinterpret_cast<const u32x4*>(As + offB[kk][i]);
         wb[kk][i] = s.v;
@@ -262,9 +281,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = TT<T>::mfma16(wb[kk][ni], xa[kk][mi], acc[ni][mi]);
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = TT<T>::mfma16(wb[kk][ni], xa[kk][mi], acc[ni][mi]);
     __syncthreads();
   }
 
@@ -276,16 +295,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   const bool stage_out = !p.out_f32 && (p.N % 8 == 0);
   T* otile = reinterpret_cast<T*>(smem);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int ml = wm * 64 + mi * 16 + fr;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int ml = wm * WROWS + mi * 16 + fr;
     const int m = bm0 + ml;
     if (m >= p.M) continue;
     const bool lora_on = p.lora_r > 0 && m >= p.lora_row0;
     const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
     const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int nl = wn * 64 + q * 32 + fq * 8;
+    for (int q = 0; q < NI / 2; ++q) {
+      const int nl = wn * WCOLS + q * 32 + fq * 8;
       const int n = gcol(nl);
       if (n >= p.N) continue;
       float v[8];
@@ -396,17 +415,18 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   if (stage_out && geglu) {
     __syncthreads();
     constexpr int NT = WM * 128;
-    {  // hidden * gelu(gate): 8 chunks of 8 output columns per row; a wave writes 8 rows x 128 contiguous bytes
-      const int c = tid & 7;
+    {  // hidden * gelu(gate): BN/16 chunks of 8 output columns per row
+      constexpr int CH = BN / 16;
       T* gout = reinterpret_cast<T*>(p.geglu_out);
 #pragma unroll
-      for (int i = 0; i < BM / (NT / 8); ++i) {
-        const int r = (tid >> 3) + i * (NT / 8);
+      for (int i = 0; i < (BM * CH) / NT; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / CH, c = idx - r * CH;
         const int m = bm0 + r;
         if (m < p.M) {
           Pack8<T> h, g, o;
           h.u = *reinterpret_cast<const u32x4*>(otile + r * OLD + c * 8);
-          g.u = *reinterpret_cast<const u32x4*>(otile + r * OLD + 64 + c * 8);
+          g.u = *reinterpret_cast<const u32x4*>(otile + r * OLD + BN / 2 + c * 8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(to_f(h.e[e]) * gelu_f(to_f(g.e[e])));
           *reinterpret_cast<u32x4*>(gout + (int64_t)m * nhalf + (bn0 >> 1) + c * 8) = o.u;
@@ -414,11 +434,12 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
       }
     }
     if (bm0 + BM > p.geglu_row0) {  // projection kept only for the rows that will be differentiated
-      const int c = tid & 15;
-      const int n = gcol(c * 8);
+      constexpr int CH = BN / 8;
 #pragma unroll
-      for (int i = 0; i < BM / (NT / 16); ++i) {
-        const int r = (tid >> 4) + i * (NT / 16);
+      for (int i = 0; i < (BM * CH) / NT; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / CH, c = idx - r * CH;
+        const int n = gcol(c * 8);
         const int m = bm0 + r;
         if (m < p.M && m >= p.geglu_row0)
           *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) =
@@ -428,11 +449,12 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   } else if (stage_out) {
     __syncthreads();
     constexpr int NT = WM * 128;
-    const int c = tid & 15;         // 16-byte chunk within the 128-column tile row
-    const int n = bn0 + c * 8;
+    constexpr int CH = BN / 8;  // 16-byte chunks per tile row
 #pragma unroll
-    for (int i = 0; i < BM / (NT / 16); ++i) {
-      const int r = (tid >> 4) + i * (NT / 16);
+    for (int i = 0; i < (BM * CH) / NT; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / CH, c = idx - r * CH;
+      const int n = bn0 + c * 8;
       const int m = bm0 + r;
       if (m < p.M && n < p.N)
         *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) =
@@ -441,18 +463,19 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   }
 }
 
-template <typename T, bool CONV, int WM>
+template <typename T, bool CONV, int WM, int NL>
 int launch_t(const GemmParams& p, hipStream_t stream) {
+  constexpr int BN = NL ? 160 : 128;
   constexpr int BM = 64 * WM;
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done && SMEM > 65536) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, CONV, WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM));
+    SMI_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, CONV, WM, NL>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM>), dim3(grid), dim3(WM * 128), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM, NL>), dim3(grid), dim3(WM * 128), SMEM, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -475,34 +498,51 @@ bool gemm2_supported(const GemmParams& p) {
   return p.N == 4 && p.ldc % 4 == 0 && !p.res && !p.rowvec;  // conv_out: one half-width column group
 }
 
+// fused GEGLU: a tile must hold matching hidden / gate column groups, i.e. N is a multiple of 2 x the tile width of
+// whichever variant launch_gemm2 will pick (N % 256 for the 128-column tiles, N % 320 for the 160-column ones)
 bool gemm2_geglu_supported(const GemmParams& p) {
   return gemm2_supported(p) && !p.conv && !p.out_f32 && !p.res && !p.rowvec && p.lora_r == 0 && p.N % 256 == 0 &&
          (reinterpret_cast<uintptr_t>(p.geglu_out) & 15) == 0;
 }
 
 int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
-  // variant: 0 = auto, 1 = 128-row tile, 2 = 256-row tile
-  int wm = 2;
+  // variant: 0 = auto, 1 = 128-row tile, 2 = 256-row tile, 3 = 64-row tile, 4 = 128 x 160 tile
+  int wm = 2, nl = 0;
+  const bool ok160 = p.N % 8 == 0 && (!p.geglu_out || p.N % 320 == 0);
   if (variant == 2) wm = 4;
   else if (variant == 0) {
     // measured (tools/bench_gemm.py): the 256-row tile only pays for very wide outputs (N >= 4096: fewer LDS bytes
     // staged per FLOP); at small N or short K the 128-row tile's extra resident workgroup per CU wins
-    const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, BN);
+    const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128);
     if (tiles256 >= 512 && p.N >= 4096 && !p.conv) wm = 4;
     if (p.conv && tiles256 >= 512) wm = 4;
+    // 128 x 160 tiles for the big grids (>= 4 tiles per CU; below that a launch is latency-bound and the smaller
+    // tile wins): cost = tiles per CU x tile area / relative tile efficiency -- reproduces the measured ratios
+    // (conv 262144 x 320: 858 vs 790 TF/s; 65536 x 640: 932 vs 1028; 16384 x 1280: 955 vs 867)
+    if (ok160 && p.N % 160 == 0 && (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) >= 1024) {
+      auto cost = [&](int bm, int bn, double eff) {
+        const int64_t tiles = (int64_t)cdiv(p.M, bm) * cdiv(p.N, bn);
+        return (double)((tiles + 255) / 256) * bm * bn / eff;
+      };
+      if (cost(128, 160, 1.04) < cost(64 * wm, 128, wm == 4 ? 1.10 : 1.0)) { wm = 2; nl = 1; }
+    }
   }
-  // small grids (e.g. M = 4096 adapted rows x N = 1280 in the backward: 320 tiles of 128x128 for 256 CUs): a 64-row
-  // tile doubles the number of workgroups (3 resident per CU at 48 KB LDS)
-  // (measured: no -- 4096x1280x1280 runs 435 TF/s on 64-row tiles vs 465 on 128-row; kept selectable, SMI_GEMM=64)
   if (variant == 3) wm = 1;
-#define GO(TT_, CV, W_) return launch_t<TT_, CV, W_>(p, stream)
+  if (variant == 4 && ok160) { wm = 2; nl = 1; }
+#define GO(TT_, CV, W_, NL_) return launch_t<TT_, CV, W_, NL_>(p, stream)
+#define PICK(TT_, CV)                            \
+  do {                                           \
+    if (nl) GO(TT_, CV, 2, 1);                   \
+    if (wm == 4) GO(TT_, CV, 4, 0);              \
+    if (wm == 1 && !CV) GO(TT_, false, 1, 0);    \
+    GO(TT_, CV, 2, 0);                           \
+  } while (0)
   if (p.dtype == DT_F16) {
-    if (p.conv) { if (wm == 4) GO(f16, true, 4); else GO(f16, true, 2); }
-    else { if (wm == 4) GO(f16, false, 4); else if (wm == 1) GO(f16, false, 1); else GO(f16, false, 2); }
+    if (p.conv) PICK(f16, true); else PICK(f16, false);
   } else {
-    if (p.conv) { if (wm == 4) GO(bf16, true, 4); else GO(bf16, true, 2); }
-    else { if (wm == 4) GO(bf16, false, 4); else if (wm == 1) GO(bf16, false, 1); else GO(bf16, false, 2); }
+    if (p.conv) PICK(bf16, true); else PICK(bf16, false);
   }
+#undef PICK
 #undef GO
   return -1;
 }
