@@ -182,6 +182,38 @@ struct smi_engine {
   smi_unet_config cfg{};
   int dtype = 0;
   hipStream_t stream = nullptr;
+  // Second stream for the LoRA weight-gradient reductions of the backward.  They are many small, latency-bound
+  // launches (rank-4 outer products over 4-16 k rows) that nothing in the dX chain waits for: each site forks them
+  // off behind an event and the main stream carries on with the dX GEMM; backward() joins before it returns.  Safe
+  // because both arenas are bump-allocated (no buffer is recycled inside one backward).  SMI_SIDE_STREAM=0 disables.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_used = false;
+  // gradient buffers the side stream still reads.  A dy can live on as another tensor's gradient (accumulate()
+  // aliases it) and then be added to IN PLACE by the main stream: such a write first joins the side stream.
+  std::vector<const void*> side_reads;
+  hipStream_t wgrad_stream(const void* dy) {
+    if (dry || prof_on || !side) return stream;  // class timing uses events on the main stream only
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(side, ev_fork, 0);
+    side_used = true;
+    side_reads.push_back(dy);
+    return side;
+  }
+  void join_side() {
+    if (!side_used) return;
+    (void)hipEventRecord(ev_join, side);
+    (void)hipStreamWaitEvent(stream, ev_join, 0);
+    side_used = false;
+    side_reads.clear();
+  }
+  void before_inplace_write(const void* g) {
+    for (const void* q : side_reads)
+      if (q == g) {
+        join_side();
+        return;
+      }
+  }
   bool dry = false;
   bool err = false;
   int max_n = 0, lat_h = 0, lat_w = 0, ctx_len = 0;
@@ -341,12 +373,14 @@ struct smi_engine {
   void* grad_slot(Ten* t, bool& had) {
     had = t->g != nullptr;
     if (!had) t->g = alloc_t(MA(t), t->cols);
+    else before_inplace_write(t->g);
     return t->g;
   }
   void accumulate(Ten* t, void* g) {
     if (!t->g) {
       t->g = g;  // alias: g is dead after its producer's closure
     } else {
+      before_inplace_write(t->g);
       RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, t->g, g, t->g, MA(t) * t->cols, stream));
     }
   }
@@ -771,22 +805,23 @@ struct smi_engine {
         g.K = L->out;
         RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0, launch_gemm(g, stream));
       }
+      hipStream_t ws = wgrad_stream(dy);  // forks behind the dxa GEMM above
       for (int s = 0; s < L->nseg; ++s) {
         const char* dys = (const char*)dy + (size_t)s * cs * esz();
         // d(up_s)[n][q] += lscale/S * sum_m dy[m][s*cs+n] * xa[m][s*r+q]
         RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, xa + s * r, rp, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
-                              cs, r, lscale, gscale + 1, scratch, stream));
+                              cs, r, lscale, gscale + 1, scratch, ws));
       }
       // d(down)[q'][k] += lscale/S * sum_m dxa[m][q'] * x[m][k] for all fused segments at once: the down matrices of
       // a fused projection are one contiguous [r_tot, in] block, so x is read once (r_tot <= 32)
       if (rtot <= 32) {
         RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa, L->rows_pad, PA(x), x->cols, d_down + L->off_down, L->in, 1, M,
-                              L->in, rtot, lscale, gscale + 1, scratch, stream));
+                              L->in, rtot, lscale, gscale + 1, scratch, ws));
       } else {
         for (int s = 0; s < L->nseg; ++s)
           RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, L->rows_pad, PA(x), x->cols,
                                 d_down + L->off_down + (int64_t)s * r * L->in, L->in, 1, M, L->in, r, lscale, gscale + 1,
-                                scratch, stream));
+                                scratch, ws));
       }
     }
     if (x->ng) {
@@ -1368,6 +1403,7 @@ struct smi_engine {
     y->g = alloc_t(MA(y), 64);
     RUN(launch_nchw_to_nhwc_scaled(dtype, d_eps, y->g, n, cfg.out_channels, HW, 64, gscale, stream));
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();
+    join_side();
     tape.clear();
     tape_valid = false;
     if (cur->overflow && !dry) {
@@ -1484,11 +1520,31 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
   }
   // the weight table is only borrowed during creation
   e->wmap.clear();
+  {
+    const char* ss = getenv("SMI_SIDE_STREAM");
+    if (!ss || strcmp(ss, "0") != 0) {
+      if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        e->side = nullptr;  // no second stream: everything stays on the caller's stream
+      }
+    }
+  }
   *out = e;
   return 0;
 }
 
-void smi_destroy(smi_engine* e) { delete e; }
+void smi_destroy(smi_engine* e) {
+  if (!e) return;
+  if (e->side) {
+    (void)hipStreamSynchronize(e->side);
+    (void)hipStreamDestroy(e->side);
+  }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  delete e;
+}
 
 int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* sample, float timestep, const void* ctx,
                              const void* text_embeds, const float* time_ids, const float* lora_down_flat,
