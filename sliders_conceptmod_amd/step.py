@@ -25,7 +25,8 @@ from . import _native, parallel
 class SliderStep:
     def __init__(self, unet, network, scheduler, *, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, max_grad_norm: float = 0.0, cfg_scale: float = 1.0,
-                 skip_dead_cfg_half: bool = False, process_group=None, batch_passes: bool = True):
+                 skip_dead_cfg_half: bool = False, process_group=None, batch_passes: bool = True,
+                 dedup_uncond: bool = False):
         self.unet, self.network, self.scheduler = unet, network, scheduler
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -37,6 +38,12 @@ class SliderStep:
         # Run the four guidance passes as ONE UNet pass (frozen samples first, adapted target samples last;
         # smi_unet_forward_batched): same per-sample arithmetic, 4x larger GEMM M, ~60 % fewer launches.
         self.batch_passes = batch_passes
+        # The three frozen passes each carry the same unconditional half (same latents, timestep and "" prompt), and
+        # the `unconditional` pass is that sample twice: 6B frozen samples, of which only 3B (4B with a real negative
+        # prompt) are distinct.  With dedup_uncond the distinct ones run once and are shared -- bit-identical results
+        # (per-sample arithmetic does not depend on batch composition: tests/test_engine_gpu.py), 8B -> 5B samples
+        # per step.  Off by default: the reference runs all of them, so the headline number does too.
+        self.dedup = bool(dedup_uncond and batch_passes and not self.skip_dead)
         flat = network.flat
         self.grad = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat)
@@ -71,6 +78,24 @@ class SliderStep:
             out[role] = c
         order = ("positive", "neutral", "negative", "target")  # adapted (target) samples LAST
         out["all"] = {k: torch.cat([out[r][k] for r in order]).contiguous() for k in out["target"]}
+        if self.dedup:
+            # distinct frozen prompts, unconditional first; then the adapted pair [unconditional, target]
+            uniq = ["unconditional"]
+            for role in ("positive", "neutral", "negative"):
+                if out["keys"][role] not in uniq:
+                    uniq.append(out["keys"][role])
+            out["uniq"] = uniq
+
+            def rows(src, key):
+                return src[key].repeat_interleave(batch_size, dim=0)
+
+            seq = uniq + ["unconditional", "target"]
+            d = {"ctx": torch.cat([rows(emb, k) for k in seq]).to(dev, dt).contiguous()}
+            if pooled is not None:
+                d["text_embeds"] = torch.cat([rows(pooled, k) for k in seq]).to(dev, dt).contiguous()
+                d["time_ids"] = torch.cat([time_ids.repeat_interleave(batch_size, dim=0)] * len(seq)).to(
+                    dev, torch.float32).contiguous()
+            out["dedup"] = d
         return out
 
     def _pass(self, engine, x, t, c, lora: bool, save: bool):
@@ -91,6 +116,8 @@ class SliderStep:
                    lr: Optional[float] = None) -> torch.Tensor:
         """One optimisation step; returns the loss as a 1-element device tensor (no host sync)."""
         lat = denoised_latents.float()
+        if self.dedup:
+            return self._train_step_dedup(lat, timestep, cond, action, eta, lr)
         x = lat if self.skip_dead else torch.cat([lat] * 2)
         x = self.scheduler.scale_model_input(x, timestep).contiguous()
         t = float(timestep)
@@ -108,6 +135,31 @@ class SliderStep:
         net.__exit__(None, None, None)
 
         return self._finish(engine, target, positive, neutral, negative, action, eta, lr)
+
+    def _train_step_dedup(self, lat, timestep, cond, action, eta, lr):
+        net = self.network
+        uniq, c = cond["uniq"], cond["dedup"]
+        B = lat.shape[0]
+        nu = len(uniq)
+        x = self.scheduler.scale_model_input(torch.cat([lat] * (nu + 2)), timestep).contiguous()
+        _, _, h, w = x.shape
+        engine = self.unet._ensure_engine((nu + 2) * B, h, w, c["ctx"].shape[1], n_adapted=2 * B)
+        net.__enter__()
+        flat, n_down, mult = net.engine_params()
+        net.__exit__(None, None, None)
+        eps = engine.forward(x, float(timestep), c["ctx"], c.get("text_embeds"), c.get("time_ids"), flat[:n_down],
+                             flat[n_down:], mult, True, n_adapted=2 * B)
+        e = {k: eps[i * B:(i + 1) * B] for i, k in enumerate(uniq)}
+
+        def cfg(pair):
+            o = torch.empty((B,) + tuple(pair.shape[1:]), dtype=torch.float32, device=pair.device)
+            _native.check(self._lib.smi_cfg_combine(_native.ptr(pair), _native.ptr(o), o.numel(), self.cfg_scale,
+                                                    _native.stream_ptr()), "smi_cfg_combine")
+            return o
+
+        outs = [cfg(torch.cat([e["unconditional"], e[cond["keys"][r]]])) for r in ("positive", "neutral", "negative")]
+        target = cfg(eps[nu * B:].contiguous())
+        return self._finish(engine, target, outs[0], outs[1], outs[2], action, eta, lr)
 
     def _train_step_batched(self, x, t, cond, action, eta, lr):
         net = self.network

@@ -165,3 +165,41 @@ def test_image_slider_two_sided_step_matches_oracle(goldens):
             den += float(b.norm() ** 2)
     rel = (num / den) ** 0.5
     assert rel < 1e-2, f"two-sided image-slider LoRA gradient vs oracle: {rel:.2e}"
+
+
+@pytest.mark.parametrize("with_negative", [True, False])
+def test_dedup_uncond_step_is_identical_to_the_full_step(with_negative):
+    """SliderStep(dedup_uncond=True) runs each distinct frozen sample once (8B -> 6B / 5B samples); loss, gradient and
+    updated parameters must equal the full 4-pass step's (same kernels on the same per-sample inputs)."""
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.model_util as MU
+    import sliders_conceptmod_amd.unet as PU
+    from sliders_conceptmod_amd.step import SliderStep
+    ocfg = CFGS["tiny_sdxl"]()
+    ou = OU.init_synthetic_(OU.UNet2DConditionModel(ocfg), seed=0)
+    res = []
+    for dedup in (False, True):
+        pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(ocfg)))
+        pu.load_state_dict(ou.state_dict())
+        pu = pu.to("cuda", torch.float16).requires_grad_(False).eval()
+        torch.manual_seed(1)
+        net = L.LoRANetwork(pu, rank=4, alpha=1.0, train_method="noxattn").to("cuda")
+        with torch.no_grad():
+            net.flat_up.copy_(torch.randn(net.flat_up.shape, generator=torch.Generator().manual_seed(2)) * 2e-2)
+        sched = MU.create_noise_scheduler("euler_a")
+        sched.set_timesteps(1000)
+        t = sched.timesteps[400]
+        g = torch.Generator().manual_seed(4)
+        keys = ["target", "positive", "neutral", "unconditional"] + (["negative"] if with_negative else [])
+        emb = {k: torch.randn(1, 77, 64, generator=g) for k in keys}
+        pooled = {k: torch.randn(1, 64, generator=g) for k in keys}
+        tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]])
+        step = SliderStep(pu, net, sched, lr=1e-3, weight_decay=1e-6, max_grad_norm=0.2, dedup_uncond=dedup)
+        cond = step.make_conditioning(emb, 2, pooled, tid)
+        lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(3)).cuda()
+        losses = [float(step.train_step(lat, t, cond, "enhance", 2.0).item()) for _ in range(2)]
+        res.append((losses, step.grad.clone(), net.flat.detach().clone()))
+    (l0, g0, p0), (l1, g1, p1) = res
+    assert l0 == pytest.approx(l1, rel=1e-6), (l0, l1)
+    assert float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max())
+    assert float((p0 - p1).abs().max()) <= 1e-7
