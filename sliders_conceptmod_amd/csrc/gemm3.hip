@@ -319,13 +319,18 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
       }
       if (lora_on) {
         const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
-        if (p.up_sq == 1 && p.lora_r == 4 && p.up_sn == 4) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow);
+        if (p.up_sq == 1 && p.up_sn == p.lora_r && (p.lora_r & 3) == 0) {
+          float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          for (int r0 = 0; r0 < p.lora_r; r0 += 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + r0);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * 4);
-            v[j] += (xv[0] * uv[0] + xv[1] * uv[1] + xv[2] * uv[2] + xv[3] * uv[3]) * p.lora_scale;
+            for (int j = 0; j < 8; ++j) {
+              const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * p.lora_r + r0);
+              d[j] += xv[0] * uv[0] + xv[1] * uv[1] + xv[2] * uv[2] + xv[3] * uv[3];
+            }
           }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += d[j] * p.lora_scale;
         } else if (p.up_sn == 1 && (p.up_sq & 3) == 0) {
           float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int r = 0; r < p.lora_r; ++r) {

@@ -95,7 +95,7 @@ def test_gemm_full_epilogue(lib, dt, r):
 def test_gemm_8phase_tile_epilogues_and_tails(lib, dt, M, N, K):
     a, w = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
     bias, res = rnd(N, dt=dt, seed=3), rnd(M, N, dt=dt, seed=4)
-    r, s = 4, 0.375
+    r, s = (8 if K == 192 else 4), 0.375  # rank 4 and rank 8 both take the vectorised LoRA epilogue
     xa = torch.randn(M, r, device="cuda")
     up = torch.randn(N, r, device="cuda") * 0.1
     c = torch.empty(M, N, device="cuda", dtype=dt)
