@@ -180,6 +180,9 @@ int smi_op_geglu(int dtype, const void* proj, void* out, const void* dout, void*
 int smi_op_gemm_geglu(int dtype, const void* A, const void* W, const void* bias, void* out, void* proj, int M, int N,
                       int K, int proj_row0, void* stream);
 int smi_op_lora_down(int dtype, const void* x, const float* a, float* xa, int m, int k, int r, void* stream);
+/* out[m, r] (fp32) = x[m, k] * s[r, k]^T on 16-bit operands, r = 16 or 32, k % 128 == 0: the engine's kernel for
+ * xa = x * lora_down^T and dxa = dy * lora_up (T/lora.py:134-138 and its backward) on the 16-bit shadow parameters */
+int smi_op_lora_skinny(int dtype, const void* x, const void* s, float* out, int m, int r, int k, void* stream);
 int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m, int k, int r, float alpha,
                       float* scratch, void* stream);
 

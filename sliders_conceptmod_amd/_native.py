@@ -75,6 +75,7 @@ _SIGS = {
     "smi_op_geglu": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p]),
     "smi_op_gemm_geglu": (C.c_int, [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "smi_op_lora_down": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "smi_op_lora_skinny": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "smi_op_lora_wgrad": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_void_p,
                                                                                    C.c_void_p]),
 }

@@ -740,7 +740,11 @@ struct smi_engine {
       g.M = (int)MA(x);
       g.N = L.rows_pad;
       g.K = L.in;
-      RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0, launch_gemm(g, stream));
+      if (dry || lora_skinny_supported(g.A, g.lda, g.W, xa, g.ldc, g.M, g.N, g.K))
+        RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0,
+             launch_lora_skinny(dtype, g.A, g.lda, g.W, xa, g.ldc, g.M, g.N, g.K, stream));
+      else
+        RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0, launch_gemm(g, stream));
     }
     GemmParams p;
     p.dtype = dtype;
@@ -803,7 +807,11 @@ struct smi_engine {
         g.M = M;
         g.N = rp;
         g.K = L->out;
-        RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0, launch_gemm(g, stream));
+        if (dry || lora_skinny_supported(g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K))
+          RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0,
+               launch_lora_skinny(dtype, g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K, stream));
+        else
+          RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0, launch_gemm(g, stream));
       }
       hipStream_t ws = wgrad_stream(dy);  // forks behind the dxa GEMM above
       for (int s = 0; s < L->nseg; ++s) {
@@ -1753,6 +1761,9 @@ int smi_op_geglu(int dtype, const void* proj, void* out, const void* dout, void*
 }
 int smi_op_lora_down(int dtype, const void* x, const float* a, float* xa, int m, int k, int r, void* stream) {
   return launch_lora_down(dtype, x, k, a, k, 1, xa, r, m, k, r, (hipStream_t)stream);
+}
+int smi_op_lora_skinny(int dtype, const void* x, const void* s, float* out, int m, int r, int k, void* stream) {
+  return launch_lora_skinny(dtype, x, k, s, out, r, m, r, k, (hipStream_t)stream);
 }
 int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m, int k, int r, float alpha,
                       float* scratch, void* stream) {

@@ -143,6 +143,10 @@ struct HostLoraPrepSite {
   int64_t off_down, off_up, dst_down, dst_up;
   int r, nseg, K, cs, rows_pad;
 };
+// out[M, R] (fp32, row stride ldo) = X[M, K] * S[R, K]^T for R = 16 / 32 (LoRA shadow products), K % 128 == 0
+bool lora_skinny_supported(const void* X, int64_t ldx, const void* S, const float* out, int ldo, int M, int R, int K);
+int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, float* out, int ldo, int M, int R, int K,
+                       hipStream_t stream);
 int launch_lora_prep(int dtype, const void* sites_dev, int n_sites, const float* down, const float* up, void* shadow,
                      hipStream_t stream);
 

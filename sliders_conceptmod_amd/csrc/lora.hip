@@ -242,4 +242,95 @@ int launch_lora_prep(int dtype, const void* sites_dev, int n_sites, const float*
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny MFMA product for the LoRA shadow operands:  out[M, R] (fp32) = X[M, K] * S[R, K]^T,  R = 16 or 32.
+//
+// These sit on the critical path of every adapted Linear (xa = x * down^T before the main GEMM, dxa = dy * up before
+// the dX GEMM) and are pure latency: 10-40 MB of X read once, a few MFLOP.  Through the tiled GEMM (32 workgroups of
+// 128 rows, 20 serial K-steps) a launch took ~28 us.  Here a workgroup owns 16 rows and its 4 waves split K, every
+// wave issues ALL of its fragment loads up front (no LDS staging, no K loop dependency), one MFMA chain, and the
+// four partial tiles meet in LDS: one memory round trip per launch, M/16 workgroups.
+// Operand maps as in the GEMMs: mfma16(S frag, X frag) -> lane (fr = l & 15, fq = l >> 4) holds out[m = fr][n = 4 fq + j].
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int NF, int STEPS>  // NF = R / 16 column fragments, STEPS = 32-deep K-steps per wave and chunk
+__global__ __launch_bounds__(256) void lora_skinny_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ S,
+                                                          float* __restrict__ out, int ldo, int M, int K) {
+  __shared__ f32x4 red[3][NF][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int m = min(m0 + fr, M - 1);           // rows past M are clamped; their results are not stored
+  const int kw = K >> 2;                       // K range of this wave: [wave * kw, (wave + 1) * kw)
+  const T* xp = X + (int64_t)m * ldx + wave * kw + fq * 8;
+  const T* sp = S + (int64_t)fr * K + wave * kw + fq * 8;
+  f32x4 acc[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < kw; k0 += 32 * STEPS) {
+    typename TT<T>::v8 xa[STEPS], sb[STEPS][NF];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+      const bool ok = k0 + 32 * i < kw;  // wave-uniform
+      Pack8<T> t;
+      t.u = ok ? *reinterpret_cast<const u32x4*>(xp + k0 + 32 * i) : u32x4{0u, 0u, 0u, 0u};
+      xa[i] = t.v;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        Pack8<T> w;
+        w.u = ok ? *reinterpret_cast<const u32x4*>(sp + (int64_t)f * 16 * K + k0 + 32 * i) : u32x4{0u, 0u, 0u, 0u};
+        sb[i][f] = w.v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = TT<T>::mfma16(sb[i][f], xa[i], acc[f]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) red[wave - 1][f][lane] = acc[f];
+  }
+  __syncthreads();
+  if (wave == 0 && m0 + fr < M) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      f32x4 v = acc[f];
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {  // fixed order: deterministic
+        const f32x4 o = red[w][f][lane];
+        v[0] += o[0];
+        v[1] += o[1];
+        v[2] += o[2];
+        v[3] += o[3];
+      }
+      *reinterpret_cast<f32x4*>(out + (int64_t)(m0 + fr) * ldo + f * 16 + fq * 4) = v;
+    }
+  }
+}
+
+bool lora_skinny_supported(const void* X, int64_t ldx, const void* S, const float* out, int ldo, int M, int R, int K) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return (R == 16 || R == 32) && K % 128 == 0 && ldx % 8 == 0 && ldo % 4 == 0 && ldo >= R && M > 0 && al16(X) &&
+         al16(S) && al16(out);
+}
+
+int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, float* out, int ldo, int M, int R, int K,
+                       hipStream_t stream) {
+  SMI_CHECK(lora_skinny_supported(X, ldx, S, out, ldo, M, R, K), "lora_skinny: unsupported layout (R=%d K=%d)", R, K);
+  const int grid = cdiv(M, 16);
+#define GO(TT_, NF_)                                                                                          \
+  hipLaunchKernelGGL((lora_skinny_kernel<TT_, NF_, 8>), dim3(grid), dim3(256), 0, stream, (const TT_*)X, ldx, \
+                     (const TT_*)S, out, ldo, M, K)
+  if (dtype == DT_F16) {
+    if (R == 16) GO(f16, 1); else GO(f16, 2);
+  } else {
+    if (R == 16) GO(bf16, 1); else GO(bf16, 2);
+  }
+#undef GO
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace smi

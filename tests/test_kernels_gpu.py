@@ -283,6 +283,18 @@ def test_lora_skinny_kernels(lib, dt, M, K, r):
     torch.testing.assert_close(dw, 1 + 0.5 * (p.t() @ x.float()), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,K,R", [(4096, 1280, 16), (1000, 640, 16), (16384, 640, 32), (4100, 3840, 16), (7, 128, 32)])
+def test_lora_skinny_product(lib, dt, M, K, R):
+    x, s = rnd(M, K, dt=dt, seed=1), rnd(R, K, dt=dt, scale=K ** -0.5, seed=2)
+    out = torch.full((M, R), 9.0, device="cuda")
+    chk(lib, lib.smi_op_lora_skinny(dcode(dt), P(x), P(s), P(out), M, R, K, None))
+    torch.testing.assert_close(out, x.float() @ s.float().t(), rtol=2e-5, atol=2e-5)  # fp32 accumulate and output
+    out2 = torch.empty_like(out)
+    chk(lib, lib.smi_op_lora_skinny(dcode(dt), P(x), P(s), P(out2), M, R, K, None))
+    assert torch.equal(out, out2)
+
+
 def test_step_ops_match_torch(lib):
     from oracle import slider_ref as R
     g = torch.Generator(device="cuda").manual_seed(0)
