@@ -301,7 +301,7 @@ static int gemm_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SMI_GEMM");
-    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : 0))))))));
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : 0))))))))));
   }
   return mode;
 }
@@ -322,13 +322,14 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   SMI_CHECK(!p.geglu_out || gemm_geglu_supported(p), "gemm: fused GEGLU not available for this shape/layout");
   // v2 (LDS-DMA staging, full-row epilogue) serves dense GEMMs and convs; SMI_GEMM=convv1 keeps convs on v1, =v1 all
   // v3 (256x256 tile, 8-phase schedule): SMI_GEMM=8ph forces it wherever its layout rules hold, =no8ph disables it
-  if ((gemm_mode() == 6 || (gemm_mode() == 0 && gemm3_wanted(p))) && gemm3_supported(p)) return launch_gemm3(p, stream);
+  if ((gemm_mode() == 6 || ((gemm_mode() == 0 || gemm_mode() == 10) && gemm3_wanted(p))) && gemm3_supported(p))
+    return launch_gemm3(p, stream);
   if (gemm_mode() != 3 && gemm2_supported(p) && (!p.conv || gemm_mode() != 4)) {
     if (p.conv) {
       SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
                 "conv: inconsistent geometry");
     }
-    return launch_gemm2(p, gemm_mode() == 8 ? 4 : ((gemm_mode() == 4 || gemm_mode() >= 6) ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode())), stream);
+    return launch_gemm2(p, gemm_mode() == 10 ? 6 : gemm_mode() == 9 ? 5 : gemm_mode() == 8 ? 4 : ((gemm_mode() == 4 || gemm_mode() >= 6) ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode())), stream);
   }
   SMI_CHECK(p.K % 8 == 0 && p.N % 4 == 0, "gemm: K %% 8 and N %% 4 must be 0 (K=%d N=%d)", p.K, p.N);
   SMI_CHECK(p.ldc % 4 == 0, "gemm: ldc %% 4 != 0");

@@ -35,13 +35,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // NL = 1: BN = 160, waves as 2 WM (M) x 1 (N), 32 x 160 per wave -- every layer width of the UNets (320 / 640 / 1280 and
 // their multiples) is a multiple of 160 but not of 128 (320 output channels = 2.5 tiles of 128), and N = 1280 splits
 // into 8 column tiles so that e.g. 4096 x 1280 is exactly 256 workgroups, one per CU.
+// NL = 2: BN = 128 with TWICE the waves (4 WM, as 2 WM (M) x 2 (N), 32 x 64 per wave): for grids of about one
+// workgroup per CU, where a lone wave per SIMD serialises its DMA issue, fragment reads and MFMAs -- two waves per
+// SIMD from the same workgroup overlap them.
 template <typename T, bool CONV, int WM, int NL>
-__global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
-  constexpr int BN = NL ? 160 : 128;
+__global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(GemmParams p) {
+  constexpr int BN = NL == 1 ? 160 : 128;
   constexpr int BM = 64 * WM;
-  constexpr int NW = WM * 2;
-  constexpr int MI = NL ? 2 : 4;    // 16-row fragments per wave
-  constexpr int NI = NL ? 10 : 4;   // 16-column fragments per wave
+  constexpr int NW = (NL == 2 ? 4 : 2) * WM;
+  constexpr int MI = NL ? 2 : 4;          // 16-row fragments per wave
+  constexpr int NI = NL == 1 ? 10 : 4;    // 16-column fragments per wave
   static_assert(((BN / 8) % NW) == 0, "W tile rows must split evenly over the waves");
   constexpr int STAGE = (BM + BN) * BK * 2;  // bytes
   constexpr int A_INSTR = (BM / 8) / NW;     // 1-KiB wave-instructions per wave for the A tile (= 4)
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = NL ? wave : wave >> 1, wn = NL ? 0 : wave & 1;
+  const int wm = NL == 1 ? wave : wave >> 1, wn = NL == 1 ? 0 : wave & 1;
   constexpr int WROWS = 16 * MI, WCOLS = 16 * NI;  // wave tile
 
   const int nbn = (p.N + BN - 1) / BN;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
   }
   if (stage_out && geglu) {
     __syncthreads();
-    constexpr int NT = WM * 128;
+    constexpr int NT = NW * 64;
     {  // hidden * gelu(gate): BN/16 chunks of 8 output columns per row
       constexpr int CH = BN / 16;
       T* gout = reinterpret_cast<T*>(p.geglu_out);
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
     }
   } else if (stage_out) {
     __syncthreads();
-    constexpr int NT = WM * 128;
+    constexpr int NT = NW * 64;
     constexpr int CH = BN / 8;  // 16-byte chunks per tile row
 #pragma unroll
     for (int i = 0; i < (BM * CH) / NT; ++i) {
@@ -470,8 +473,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_glds_kernel(GemmParams p) {
 
 template <typename T, bool CONV, int WM, int NL>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-  constexpr int BN = NL ? 160 : 128;
+  constexpr int BN = NL == 1 ? 160 : 128;
   constexpr int BM = 64 * WM;
+  constexpr int NW = (NL == 2 ? 4 : 2) * WM;
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done && SMEM > 65536) {
@@ -480,7 +484,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
     attr_done = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM, NL>), dim3(grid), dim3(WM * 128), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM, NL>), dim3(grid), dim3(NW * 64), SMEM, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -511,11 +515,12 @@ bool gemm2_geglu_supported(const GemmParams& p) {
 }
 
 int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
-  // variant: 0 = auto, 1 = 128-row tile, 2 = 256-row tile, 3 = 64-row tile, 4 = 128 x 160 tile
+  // variant: 0 = auto, 1 = 128-row tile, 2 = 256-row tile, 3 = 64-row tile, 4 = 128 x 160 tile,
+  //          5 = 128 x 128 tile with 8 waves
   int wm = 2, nl = 0;
   const bool ok160 = p.N % 8 == 0 && (!p.geglu_out || p.N % 320 == 0);
   if (variant == 2) wm = 4;
-  else if (variant == 0) {
+  else if (variant == 0 || variant == 6) {
     // measured (tools/bench_gemm.py): the 256-row tile only pays for very wide outputs (N >= 4096: fewer LDS bytes
     // staged per FLOP); at small N or short K the 128-row tile's extra resident workgroup per CU wins
     const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128);
@@ -532,11 +537,16 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
       if (cost(128, 160, 1.04) < cost(64 * wm, 128, wm == 4 ? 1.10 : 1.0)) { wm = 2; nl = 1; }
     }
   }
+  // the 128 x 128 tile runs with 8 waves (measured better than 4 on every shape of tools/bench_gemm.py, most with
+  // an epilogue: 4096 x 1280 x 1280 + bias + residual 24.7 vs 27.8 us); variant 6 = auto with the 4-wave form
+  if ((variant == 0 || variant == 1) && wm == 2 && nl == 0) nl = 2;
   if (variant == 3) wm = 1;
   if (variant == 4 && ok160) { wm = 2; nl = 1; }
+  if (variant == 5) { wm = 2; nl = 2; }
 #define GO(TT_, CV, W_, NL_) return launch_t<TT_, CV, W_, NL_>(p, stream)
 #define PICK(TT_, CV)                            \
   do {                                           \
+    if (nl == 2) GO(TT_, CV, 2, 2);              \
     if (nl) GO(TT_, CV, 2, 1);                   \
     if (wm == 4) GO(TT_, CV, 4, 0);              \
     if (wm == 1 && !CV) GO(TT_, false, 1, 0);    \
