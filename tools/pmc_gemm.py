@@ -1,9 +1,10 @@
+"""A few GEMM launches for rocprofv3 --pmc runs (SMI_GEMM selects the kernel generation)."""
 import ctypes as C, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sliders_conceptmod_amd import _native
 lib = _native.lib()
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-for (M, N, K, epi) in [(16384, 1280, 1280, 1), (16384, 3840, 1280, 0), (65536, 640, 640, 1)]:
+for (M, N, K, epi) in [(8192, 8192, 8192, 0), (16384, 10240, 1280, 0), (16384, 3840, 1280, 1)]:
     a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
     c = torch.empty(M, N, device="cuda", dtype=torch.float16)
     bias = torch.randn(N, device="cuda").half() if epi else None
@@ -11,10 +12,3 @@ for (M, N, K, epi) in [(16384, 1280, 1280, 1), (16384, 3840, 1280, 0), (65536, 6
     for _ in range(3):
         lib.smi_op_gemm(0, P(a), P(w), P(c), M, N, K, P(bias), P(res), None, None, 0, 0.0, 0, None)
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(10):
-        lib.smi_op_gemm(0, P(a), P(w), P(c), M, N, K, P(bias), P(res), None, None, 0, 0.0, 0, None)
-    e.record(); torch.cuda.synchronize()
-    t = s.elapsed_time(e) / 10 * 1e-3
-    print(f"gemm {M}x{N}x{K} epi={epi}: {t*1e6:.1f} us {2.0*M*N*K/t/1e12:.1f} TF/s", flush=True)
