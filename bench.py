@@ -253,6 +253,22 @@ def main():
     if rank == 0:
         log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step; profiling one step")
 
+    # ---- second number: the no-grad pre-roll the reference runs before every step
+    # (diffusion / diffusion_xl, adaptor on, CFG batch 2B), with timesteps_to fixed at its mean
+    n_pre = 6 if xl else 25
+    pre_sched = MU.create_noise_scheduler(sched_name)
+    pre_sched.set_timesteps(12 if xl else 50)
+    pre_step = SliderStep(unet, net, pre_sched, cfg_scale=1.0)
+    torch.manual_seed(7)
+    pre_step.preroll(denoised, cond, 1, 3.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pre_step.preroll(denoised, cond, n_pre, 3.0)
+    torch.cuda.synchronize()
+    preroll_ms = (time.perf_counter() - t0) * 1e3
+    if rank == 0:
+        log(f"pre-roll of {n_pre} forwards: {preroll_ms:.1f} ms")
+
     # ---- separate profiled step: per-kernel-class device time from HIP events on the launch stream
     engine = unet._engine
     engine.profile_enable(True)
@@ -283,6 +299,9 @@ def main():
                        "1 batched UNet call (3 frozen + 1 adapted sub-batches)"},
             "samples_per_s": args.steps * B * world / elapsed,
             "loss": loss_val,
+            "preroll": {"forwards": n_pre, "ms": preroll_ms, "unet_batch": 2 * B,
+                        "note": "no-grad diffusion(_xl) pre-roll at its mean length, adaptor on; NOT part of `value`",
+                        "steps_per_s_with_preroll": world / ((ms_per_step + preroll_ms) * 1e-3)},
             "step_algorithmic_tflop": step_flops / 1e12,
             "step_tflops_achieved": step_flops / 1e12 / (ms_per_step * 1e-3),
             "step_frac_of_mfma_peak": step_flops / 1e12 / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS,

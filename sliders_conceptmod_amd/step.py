@@ -76,6 +76,15 @@ class SliderStep:
                 c["text_embeds"] = pe.to(dev, dt).contiguous()
                 c["time_ids"] = ti.to(dev, torch.float32).contiguous()
             out[role] = c
+        # the pre-roll always runs the doubled [unconditional, target] batch (guidance 3 / train.cfg there)
+        tf = {"ctx": torch.cat([emb["unconditional"], emb["target"]]).repeat_interleave(batch_size, dim=0)
+              .to(dev, dt).contiguous()}
+        if pooled is not None:
+            tf["text_embeds"] = torch.cat([pooled["unconditional"], pooled["target"]]).repeat_interleave(
+                batch_size, dim=0).to(dev, dt).contiguous()
+            tf["time_ids"] = torch.cat([time_ids, time_ids]).repeat_interleave(batch_size, dim=0).to(
+                dev, torch.float32).contiguous()
+        out["target_full"] = tf
         order = ("positive", "neutral", "negative", "target")  # adapted (target) samples LAST
         out["all"] = {k: torch.cat([out[r][k] for r in order]).contiguous() for k in out["target"]}
         if self.dedup:
@@ -111,6 +120,32 @@ class SliderStep:
         _native.check(self._lib.smi_cfg_combine(_native.ptr(eps), _native.ptr(out), out.numel(), self.cfg_scale,
                                                 _native.stream_ptr()), "smi_cfg_combine")
         return out
+
+    @torch.no_grad()
+    def preroll(self, latents: torch.Tensor, cond: dict, total_timesteps: int, guidance_scale: float,
+                start_timesteps: int = 0) -> torch.Tensor:
+        """The no-grad pre-roll `diffusion(_xl)` (train_util.py:306-327, 677-708): for each of the first
+        `total_timesteps` scheduler timesteps, predict_noise(_xl) with the adaptor ON at `guidance_scale` on the target
+        prompt pair, then scheduler.step(...).prev_sample.  Same arithmetic as train_util.diffusion(_xl) on this
+        engine, without autograd bookkeeping; returns the denoised latents (fp32)."""
+        net = self.network
+        lat = latents.float()
+        c = cond["target_full"]
+        B = lat.shape[0]
+        net.__enter__()
+        flat, n_down, mult = net.engine_params()
+        net.__exit__(None, None, None)
+        for timestep in self.scheduler.timesteps[start_timesteps:total_timesteps]:
+            x = self.scheduler.scale_model_input(torch.cat([lat] * 2), timestep).contiguous()
+            _, _, h, w = x.shape
+            engine = self.unet._ensure_engine(2 * B, h, w, c["ctx"].shape[1])
+            eps = engine.forward(x, float(timestep), c["ctx"], c.get("text_embeds"), c.get("time_ids"), flat[:n_down],
+                                 flat[n_down:], mult, False)
+            pred = torch.empty((B,) + tuple(eps.shape[1:]), dtype=torch.float32, device=eps.device)
+            _native.check(self._lib.smi_cfg_combine(_native.ptr(eps), _native.ptr(pred), pred.numel(),
+                                                    float(guidance_scale), _native.stream_ptr()), "smi_cfg_combine")
+            lat = self.scheduler.step(pred, timestep, lat).prev_sample
+        return lat
 
     def train_step(self, denoised_latents: torch.Tensor, timestep, cond: dict, action: str, eta: float,
                    lr: Optional[float] = None) -> torch.Tensor:

@@ -203,3 +203,47 @@ def test_dedup_uncond_step_is_identical_to_the_full_step(with_negative):
     assert l0 == pytest.approx(l1, rel=1e-6), (l0, l1)
     assert float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max())
     assert float((p0 - p1).abs().max()) <= 1e-7
+
+
+def test_native_preroll_matches_the_drop_in_diffusion_xl():
+    """SliderStep.preroll == train_util.diffusion_xl (the reference's pre-roll loop, T/train_util.py:677-708) on the
+    same engine: same UNet calls, CFG mix and Euler-a steps (host RNG seeded identically)."""
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.model_util as MU
+    import sliders_conceptmod_amd.unet as PU
+    from sliders_conceptmod_amd import train_util as TU
+    from sliders_conceptmod_amd.step import SliderStep
+    ocfg = CFGS["tiny_sdxl"]()
+    ou = OU.init_synthetic_(OU.UNet2DConditionModel(ocfg), seed=0)
+    pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(ocfg)))
+    pu.load_state_dict(ou.state_dict())
+    pu = pu.to("cuda", torch.float16).requires_grad_(False).eval()
+    torch.manual_seed(1)
+    net = L.LoRANetwork(pu, rank=4, alpha=1.0, train_method="noxattn").to("cuda")
+    with torch.no_grad():
+        net.flat_up.copy_(torch.randn(net.flat_up.shape, generator=torch.Generator().manual_seed(2)) * 2e-2)
+    g = torch.Generator().manual_seed(4)
+    keys = ["target", "positive", "neutral", "unconditional"]
+    emb = {k: torch.randn(1, 77, 64, generator=g) for k in keys}
+    pooled = {k: torch.randn(1, 64, generator=g) for k in keys}
+    tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]])
+    lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(3)).cuda()
+    out = []
+    for native in (True, False):
+        sched = MU.create_noise_scheduler("euler_a")
+        sched.set_timesteps(12)
+        lat0 = lat * sched.init_noise_sigma
+        torch.manual_seed(11)
+        if native:
+            step = SliderStep(pu, net, sched)
+            cond = step.make_conditioning(emb, 2, pooled, tid)
+            out.append(step.preroll(lat0, cond, 4, 3.0))
+        else:
+            te = TU.concat_embeddings(emb["unconditional"], emb["target"], 2).cuda().half()
+            pe = TU.concat_embeddings(pooled["unconditional"], pooled["target"], 2).cuda().half()
+            ti = TU.concat_embeddings(tid, tid, 2).cuda()
+            with net:
+                out.append(TU.diffusion_xl(pu, sched, lat0, te, pe, ti, guidance_scale=3.0, total_timesteps=4))
+    a, b = out
+    assert torch.isfinite(a).all()
+    assert float((a - b.float()).abs().max()) <= 1e-5 * float(b.abs().max())
