@@ -74,3 +74,30 @@ def test_real_architecture_forward_and_lora_gradients(model):
     assert e0 < 3e-3 and e1 < 3e-3, (e0, e1)
     assert rel(got, got0) > 1e-4  # the adaptor does something
     assert eg < 1.5e-2, eg
+
+
+def test_kernel_generations_agree_at_headline_size(tmp_path):
+    """Size-independent property at BASELINE's full size (SD-XL 1024^2, B = 2, rank 4: 16 UNet samples per pass, where
+    the CPU oracle would need hours): every GEMM generation accumulates over K in the same order and applies the same
+    epilogue arithmetic, so a whole train step run with the tile selection forced to the plain 128 x 128 LDS-DMA kernel
+    on one stream must give the SAME loss, LoRA gradient and updated parameters as the default selection (256 x 256
+    8-phase kernel, 128 x 160 tiles, skinny LoRA products, second stream for the weight gradients).  A race or an
+    indexing slip in any of those at the real shapes shows up here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, env in (("default", {}), ("plain", {"SMI_GEMM": "128", "SMI_SIDE_STREAM": "0"})):
+        out = tmp_path / f"{name}.pt"
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fullsize_digest.py"), "--out", str(out)],
+                           env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(out, weights_only=True))
+    a, b = outs
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    assert torch.isfinite(a["grad"]).all() and float(a["grad"].abs().max()) > 0
+    assert torch.equal(a["grad"], b["grad"]), f"max |diff| {float((a['grad'] - b['grad']).abs().max()):.3e}"
+    assert torch.equal(a["flat"], b["flat"])
