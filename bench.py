@@ -178,10 +178,18 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # rehearsal on a one-GPU box (tests only): SMI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo, which
+    # RCCL would refuse (duplicate GPU); the measured path is always one rank per GPU over RCCL
+    rehearsal = os.environ.get("SMI_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sliders_conceptmod_amd import build as smi_build
     if rank == 0:
