@@ -1,3 +1,4 @@
+"""Attention forward launches for rocprofv3 --pmc runs."""
 import ctypes as C, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sliders_conceptmod_amd import _native
@@ -9,10 +10,3 @@ for (B, H, N, D) in [(16, 10, 4096, 64), (16, 20, 1024, 64)]:
     for _ in range(3):
         lib.smi_op_attention_fwd(0, P(q), P(k), P(v), P(o), P(lse), B, H, N, N, D, D ** -0.5, None)
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(5):
-        lib.smi_op_attention_fwd(0, P(q), P(k), P(v), P(o), P(lse), B, H, N, N, D, D ** -0.5, None)
-    e.record(); torch.cuda.synchronize()
-    t = s.elapsed_time(e) / 5 * 1e-3
-    print(f"attn fwd B{B} H{H} N{N} D{D}: {t*1e6:.1f} us {4.0*B*H*N*N*D/t/1e12:.1f} TF/s", flush=True)
