@@ -15,6 +15,7 @@
 // into out-of-range buffer offsets, which the hardware range check returns as zeros.
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 #include "kernels.h"
 
@@ -317,9 +318,124 @@ static bool gemm3_wanted(const GemmParams& p) {
 
 bool gemm_geglu_supported(const GemmParams& p) { return gemm_mode() != 3 && gemm2_geglu_supported(p); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile autotuning.  All kernel generations / tile layouts give bit-identical results (same K order, same epilogue
+// arithmetic: tests/test_fullsize_gpu.py), so which one runs is purely a speed question, and the heuristics above were
+// fitted to a handful of SD-XL shapes.  The first time a (shape, epilogue) key is launched the candidates its layout
+// allows are timed with HIP events on the launch stream (2 launches each after one warm-up; this synchronises with
+// the host, once per key, during the first step) and the winner is cached for the life of the process.  A candidate
+// must beat the heuristic choice by 3 % to replace it.  Tuning launches are harmless: every launch fully rewrites
+// its outputs from read-only inputs, except in-place accumulation (res == C), which is timed into a scratch output.
+// SMI_GEMM_TUNE=0 turns it off; any SMI_GEMM override does too.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct TuneKey {
+  int v[14];
+  bool operator==(const TuneKey& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
+};
+struct TuneHash {
+  size_t operator()(const TuneKey& k) const {
+    size_t h = 1469598103934665603ull;
+    for (int x : k.v) h = (h ^ (size_t)(unsigned)x) * 1099511628211ull;
+    return h;
+  }
+};
+std::unordered_map<TuneKey, int, TuneHash>& tune_cache() {
+  static std::unordered_map<TuneKey, int, TuneHash> c;
+  return c;
+}
+bool tune_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("SMI_GEMM_TUNE");
+    on = (e && !strcmp(e, "0")) ? 0 : 1;
+  }
+  return on == 1;
+}
+// candidate codes: 0 = heuristic, 1 = v2 128x128 (8 waves), 2 = v2 256x128, 4 = v2 128x160, 100 = v3 8-phase
+int launch_candidate(const GemmParams& p, int cand, hipStream_t stream) {
+  if (cand == 100) return launch_gemm3(p, stream);
+  if (cand == 0) {
+    if (gemm3_wanted(p) && gemm3_supported(p)) return launch_gemm3(p, stream);
+    return launch_gemm2(p, 0, stream);
+  }
+  return launch_gemm2(p, cand, stream);
+}
+int tuned_choice(const GemmParams& p, hipStream_t stream) {
+  TuneKey key;
+  const int kv[14] = {(int)p.dtype, (int)p.conv, p.M, p.N, p.K, (int)(p.conv ? p.Cin : p.lda),
+                      (int)(p.stride * 4 + p.upsample * 2 + p.transposed), (int)(p.res != nullptr), p.lora_r,
+                      (int)(p.geglu_out != nullptr), (int)p.out_f32, (int)(p.bias != nullptr),
+                      (int)(p.rowvec != nullptr), (int)(p.conv ? p.Hin * 65536 + p.Win : p.ldc)};
+  memcpy(key.v, kv, sizeof(kv));
+  auto& cache = tune_cache();
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int cands[5], nc = 0;
+  cands[nc++] = 0;
+  const bool plain_conv = p.conv && p.stride == 1 && !p.upsample && !p.transposed;
+  if (!p.conv || plain_conv) {
+    cands[nc++] = 1;
+    if ((int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 128) cands[nc++] = 2;
+    if (p.N % 160 == 0 && (!p.geglu_out || p.N % 320 == 0)) cands[nc++] = 4;
+    if (gemm3_supported(p) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) cands[nc++] = 100;
+  }
+  int best = 0;
+  if (nc > 1) {
+    GemmParams q = p;
+    void* tmp = nullptr;
+    if (q.res == q.C) {  // in-place accumulation is not repeatable: the tuning launches write to a scratch output
+      const size_t bytes = ((size_t)(p.M - 1) * p.ldc + p.N) * (p.out_f32 ? 4 : 2);
+      if (hipMalloc(&tmp, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        cache[key] = 0;
+        return 0;
+      }
+      q.C = tmp;
+    }
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      (void)hipGetLastError();
+      if (tmp) (void)hipFree(tmp);
+      cache[key] = 0;
+      return 0;
+    }
+    float tbest = 0.f, t0 = 0.f;
+    for (int i = 0; i < nc; ++i) {
+      if (launch_candidate(q, cands[i], stream) != 0) continue;  // warm-up (also sets the LDS attribute once)
+      (void)hipEventRecord(a, stream);
+      (void)launch_candidate(q, cands[i], stream);
+      (void)launch_candidate(q, cands[i], stream);
+      (void)hipEventRecord(b, stream);
+      if (hipEventSynchronize(b) != hipSuccess) break;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, a, b);
+      if (i == 0) { t0 = tbest = ms; continue; }
+      if (ms < 0.97f * t0 && ms < tbest) { tbest = ms; best = cands[i]; }
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (tmp) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipFree(tmp);
+    }
+    (void)hipGetLastError();
+  }
+  cache[key] = best;
+  return best;
+}
+}  // namespace
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
   SMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   SMI_CHECK(!p.geglu_out || gemm_geglu_supported(p), "gemm: fused GEGLU not available for this shape/layout");
+  if (gemm_mode() == 0 && tune_enabled() && gemm2_supported(p) && (int64_t)p.M * p.N >= (1 << 20)) {
+    if (p.conv) {
+      SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
+                "conv: inconsistent geometry");
+    }
+    return launch_candidate(p, tuned_choice(p, stream), stream);
+  }
   // v2 (LDS-DMA staging, full-row epilogue) serves dense GEMMs and convs; SMI_GEMM=convv1 keeps convs on v1, =v1 all
   // v3 (256x256 tile, 8-phase schedule): SMI_GEMM=8ph forces it wherever its layout rules hold, =no8ph disables it
   if ((gemm_mode() == 6 || ((gemm_mode() == 0 || gemm_mode() == 10) && gemm3_wanted(p))) && gemm3_supported(p))
