@@ -354,8 +354,8 @@ bool tune_enabled() {
 }
 // candidate codes: 0 = heuristic, 1 = v2 128x128 (8 waves), 2 = v2 256x128, 4 = v2 128x160, 100 = v3 8-phase
 int launch_candidate(const GemmParams& p, int cand, hipStream_t stream) {
-  if (cand == 100) return launch_gemm3(p, stream);
-  if (cand == 0) {
+  if (cand == 100 && gemm3_supported(p)) return launch_gemm3(p, stream);  // (layout re-checked: the key is shape-only)
+  if (cand == 0 || cand == 100) {
     if (gemm3_wanted(p) && gemm3_supported(p)) return launch_gemm3(p, stream);
     return launch_gemm2(p, 0, stream);
   }
