@@ -207,3 +207,37 @@ def test_batched_guidance_pass_equals_separate_passes(model):
         torch.testing.assert_close(out[i * n:(i + 1) * n], sep[i], rtol=0, atol=0)
     assert float(g_sep.abs().max()) > 0
     torch.testing.assert_close(g_bat, g_sep, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+def test_rank8_and_ragged_nonsquare_latents(model):
+    """BASELINE configs[3] trains rank 8; and latents need not be square or a multiple of the tile sizes: 24 x 40 latents
+    (ragged attention key tiles: 960 / 240 / 60 tokens; conv rows that are not multiples of 128) with a rank-8 network,
+    forward and LoRA gradients against the oracle."""
+    dtype = torch.float16
+    ocfg, ou, onet, pu, pnet = build_pair(model, dtype, method="noxattn", rank=8)
+    g = torch.Generator().manual_seed(3)
+    n, H, W = 2, 24, 40
+    x = torch.randn(n, 4, H, W, generator=g)
+    ctx = torch.randn(n, 77, ocfg.cross_attention_dim, generator=g)
+    add = None
+    if ocfg.addition_embed_type == "text_time":
+        pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
+        add = {"text_embeds": torch.randn(n, pdim, generator=g),
+               "time_ids": torch.tensor([[H * 8.0, W * 8.0, 0, 0, H * 8.0, W * 8.0]] * n)}
+    gy = torch.randn(n, 4, H, W, generator=g) * 1e-4
+    with onet:
+        ref = ou(x, 499.0, ctx, add).sample
+    (ref * gy).sum().backward()
+    with pnet:
+        got = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+    (got * gy.cuda()).sum().backward()
+    assert rel(got, ref) < LOOSE[dtype], f"forward {rel(got, ref):.2e}"
+    num = den = 0.0
+    for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+        assert lp.lora_down.weight.shape == (8, lo.lora_down.weight.shape[1])
+        for a, b in ((lp.lora_down.grad, lo.lora_down.weight.grad), (lp.lora_up.grad, lo.lora_up.weight.grad)):
+            num += (a.detach().cpu() - b).norm().item() ** 2
+            den += b.norm().item() ** 2
+    glob = (num / den) ** 0.5
+    assert glob < 8e-3, f"rank-8 / ragged global LoRA-grad rel err {glob:.3e}"

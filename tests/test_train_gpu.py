@@ -247,3 +247,26 @@ def test_native_preroll_matches_the_drop_in_diffusion_xl():
     a, b = out
     assert torch.isfinite(a).all()
     assert float((a - b.float()).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_two_rank_bench_flow_on_one_gpu():
+    """The N > 1 path of bench.py (one process per rank, barrier + max-over-ranks timing, LoRA-gradient all-reduce before
+    the clip, rank 0 prints the JSON line) rehearsed with two ranks sharing this box's single GPU over gloo
+    (SMI_BENCH_ONE_DEVICE=1; RCCL refuses two ranks on one device).  The measured path is one rank per GPU over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMI_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--config", "tiny_sdxl", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]  # whole-job aggregate: world / step time
+    assert d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
