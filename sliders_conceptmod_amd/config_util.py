@@ -1,91 +1,75 @@
-"""YAML config schema of the reference, field for field (conceptmod/textsliders/config_util.py:14-107;
-trainscripts/imagesliders/config_util.py:14-104 differs only in TrainConfig.lr default 1e-4)."""
+"""The reference's YAML configuration surface (conceptmod/textsliders/config_util.py:14-107; the image-slider copy,
+trainscripts/imagesliders/config_util.py:14-104, differs only in the `train.lr` default, 1e-4).
+
+The schema is data: one table of sections -> fields -> (type, default), turned into pydantic models of the reference's
+names, so a config written for the reference validates here field for field (and a typo'd key or a wrong type fails
+with the same pydantic ValidationError)."""
 from typing import Literal, Optional
 
 import torch
 import yaml
-from pydantic import BaseModel
+from pydantic import BaseModel, create_model
 
 from .lora import TRAINING_METHODS
 
+_DTYPES = {torch.float32: ("fp32", "float32"), torch.float16: ("fp16", "float16"), torch.bfloat16: ("bf16", "bfloat16")}
 PRECISION_TYPES = Literal["fp32", "fp16", "bf16", "float32", "float16", "bfloat16"]
 NETWORK_TYPES = Literal["lierla", "c3lier"]
+_SCHEDULERS = Literal["ddim", "ddpm", "lms", "euler_a", "builtin"]
+
+_REQUIRED = ...
+# section -> {field: (annotation, default)}; the YAML key of a section is its lower-cased name without "Config"
+_SECTIONS = {
+    "PretrainedModelConfig": dict(name_or_path=(str, _REQUIRED), v2=(bool, False), v_pred=(bool, False),
+                                  clip_skip=(Optional[int], None)),
+    "NetworkConfig": dict(type=(NETWORK_TYPES, "lierla"), rank=(int, 4), alpha=(float, 1.0),
+                          training_method=(TRAINING_METHODS, "full")),
+    "TrainConfig": dict(precision=(PRECISION_TYPES, "bfloat16"), noise_scheduler=(_SCHEDULERS, "ddim"),
+                        iterations=(int, 500), lr=(float, 1e-3), eta_min=(float, 1e-4),
+                        lambda_similarity=(float, 0.1), optimizer=(str, "adamw"), optimizer_args=(str, ""),
+                        lr_scheduler=(str, "constant"), cfg=(float, 1.0), max_denoising_steps=(int, 50)),
+    "SaveConfig": dict(name=(str, "untitled"), path=(str, "./output"), per_steps=(int, 200),
+                       precision=(PRECISION_TYPES, "float32")),
+    "LoggingConfig": dict(use_wandb=(bool, False), verbose=(bool, False)),
+    "OtherConfig": dict(use_xformers=(bool, False)),
+}
 
 
-class PretrainedModelConfig(BaseModel):
-    name_or_path: str
-    v2: bool = False
-    v_pred: bool = False
-    clip_skip: Optional[int] = None
+def _section(name: str):
+    model = create_model(name, __base__=BaseModel, **_SECTIONS[name])
+    model.__module__ = __name__
+    return model
 
 
-class NetworkConfig(BaseModel):
-    type: NETWORK_TYPES = "lierla"
-    rank: int = 4
-    alpha: float = 1.0
-    training_method: TRAINING_METHODS = "full"
+PretrainedModelConfig = _section("PretrainedModelConfig")
+NetworkConfig = _section("NetworkConfig")
+TrainConfig = _section("TrainConfig")
+SaveConfig = _section("SaveConfig")
+LoggingConfig = _section("LoggingConfig")
+OtherConfig = _section("OtherConfig")
 
+# sections a config file may leave out (or set to null); they are filled with their defaults after validation
+_OPTIONAL = {"train": TrainConfig, "save": SaveConfig, "logging": LoggingConfig, "other": OtherConfig}
 
-class TrainConfig(BaseModel):
-    precision: PRECISION_TYPES = "bfloat16"
-    noise_scheduler: Literal["ddim", "ddpm", "lms", "euler_a", "builtin"] = "ddim"
-    iterations: int = 500
-    lr: float = 1e-3
-    eta_min: float = 1e-4
-    lambda_similarity: float = 0.1
-    optimizer: str = "adamw"
-    optimizer_args: str = ""
-    lr_scheduler: str = "constant"
-    cfg: float = 1.0
-    max_denoising_steps: int = 50
-
-
-class SaveConfig(BaseModel):
-    name: str = "untitled"
-    path: str = "./output"
-    per_steps: int = 200
-    precision: PRECISION_TYPES = "float32"
-
-
-class LoggingConfig(BaseModel):
-    use_wandb: bool = False
-    verbose: bool = False
-
-
-class OtherConfig(BaseModel):
-    use_xformers: bool = False
-
-
-class RootConfig(BaseModel):
-    prompts_file: str
-    pretrained_model: PretrainedModelConfig
-    network: NetworkConfig
-    train: Optional[TrainConfig] = None
-    save: Optional[SaveConfig] = None
-    logging: Optional[LoggingConfig] = None
-    other: Optional[OtherConfig] = None
+RootConfig = create_model(
+    "RootConfig", __base__=BaseModel, prompts_file=(str, _REQUIRED),
+    pretrained_model=(PretrainedModelConfig, _REQUIRED), network=(NetworkConfig, _REQUIRED),
+    **{key: (Optional[cls], None) for key, cls in _OPTIONAL.items()})
+RootConfig.__module__ = __name__
 
 
 def parse_precision(precision: str) -> torch.dtype:
-    if precision in ("fp32", "float32"):
-        return torch.float32
-    if precision in ("fp16", "float16"):
-        return torch.float16
-    if precision in ("bf16", "bfloat16"):
-        return torch.bfloat16
+    for dtype, names in _DTYPES.items():
+        if precision in names:
+            return dtype
     raise ValueError(f"Invalid precision type: {precision}")
 
 
-def load_config_from_yaml(config_path: str) -> RootConfig:
-    with open(config_path, "r") as f:
-        config = yaml.safe_load(f)
-    root = RootConfig(**config)
-    if root.train is None:
-        root.train = TrainConfig()
-    if root.save is None:
-        root.save = SaveConfig()
-    if root.logging is None:
-        root.logging = LoggingConfig()
-    if root.other is None:
-        root.other = OtherConfig()
+def load_config_from_yaml(config_path: str):
+    with open(config_path, "r") as fh:
+        raw = yaml.safe_load(fh)  # plain data only: nothing in the file is executed
+    root = RootConfig(**raw)
+    for key, cls in _OPTIONAL.items():
+        if getattr(root, key) is None:
+            setattr(root, key, cls())
     return root

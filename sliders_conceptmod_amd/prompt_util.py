@@ -4,43 +4,53 @@ four-prompt upstream form trainscripts/imagesliders/prompt_util.py:86-148).
 One loss serves both formulations: `negative` is optional and falls back to `unconditional`, which reproduces
 the fork's five-prompt call (`negative_latents=`, train_lora_xl.py:334-339) and the upstream four-prompt call
 (`unconditional_latents=`, train_lora.py:284-289) -- the stale 6-argument call in the fork's own train_lora.py
- works again through this."""
-import copy
-from typing import Literal, Optional, Union
+ works again through this.
+
+    loss = loss_fn(target, neutral + sign * guidance_scale * (positive - negative)),   sign = -1 erase, +1 enhance"""
+from typing import Dict, Literal, Optional, Sequence, Union
 
 import torch
 import yaml
 from pydantic import BaseModel, model_validator
 
 ACTION_TYPES = Literal["erase", "enhance"]
+_ACTION_SIGN = {"erase": -1.0, "enhance": +1.0}
+# the prompt fields an `--attributes` prefix is applied to
+_PROMPT_KEYS = ("target", "positive", "neutral", "negative", "unconditional")
 
 
 class PromptEmbedsXL:
-    def __init__(self, *args) -> None:
-        self.text_embeds = args[0]
-        self.pooled_embeds = args[1]
+    """SD-XL conditioning of one prompt: (token embeddings of both encoders concatenated, pooled embedding)."""
+    __slots__ = ("text_embeds", "pooled_embeds")
+
+    def __init__(self, text_embeds, pooled_embeds) -> None:
+        self.text_embeds, self.pooled_embeds = text_embeds, pooled_embeds
 
 
 PROMPT_EMBEDDING = Union[torch.Tensor, PromptEmbedsXL]
 
 
 class PromptEmbedsCache:
+    """prompt string -> embedding; a miss reads as None (the trainers test `cache[p] is None` before encoding)."""
+
     def __init__(self):
-        self.prompts = {}
+        self.prompts: Dict[str, PROMPT_EMBEDDING] = {}
 
-    def __setitem__(self, name: str, value) -> None:
-        self.prompts[name] = value
+    def __getitem__(self, prompt: str):
+        return self.prompts.get(prompt)
 
-    def __getitem__(self, name: str):
-        return self.prompts.get(name)
+    def __setitem__(self, prompt: str, embedding) -> None:
+        self.prompts[prompt] = embedding
 
 
 class PromptSettings(BaseModel):
+    """One entry of prompts.yaml.  Only `target` is mandatory: `positive` defaults to it, `neutral` to `unconditional`
+    (itself "" by default), `negative` stays None (= use `unconditional` in the loss)."""
     target: str
-    positive: Optional[str] = None  # if None, target will be used
+    positive: Optional[str] = None
     negative: Optional[str] = None
     unconditional: str = ""
-    neutral: Optional[str] = None  # if None, unconditional will be used
+    neutral: Optional[str] = None
     action: ACTION_TYPES = "erase"
     guidance_scale: float = 1.0
     resolution: int = 512
@@ -50,71 +60,61 @@ class PromptSettings(BaseModel):
 
     @model_validator(mode="before")
     @classmethod
-    def fill_prompts(cls, values):
-        keys = values.keys()
-        if "target" not in keys:
+    def _defaults_from_other_prompts(cls, raw):
+        if "target" not in raw:
             raise ValueError("target must be specified")
-        if "positive" not in keys:
-            values["positive"] = values["target"]
-        if "unconditional" not in keys:
-            values["unconditional"] = ""
-        if "neutral" not in keys:
-            values["neutral"] = values["unconditional"]
-        return values
+        raw.setdefault("positive", raw["target"])
+        raw.setdefault("unconditional", "")
+        raw.setdefault("neutral", raw["unconditional"])
+        return raw
 
 
 class PromptEmbedsPair:
+    """The embeddings of one prompt entry plus its loss.  Accepts the fork's 7-argument construction
+    (..., neutral, negative, settings) and upstream's 6-argument one (..., neutral, settings)."""
+    _COPIED = ("guidance_scale", "resolution", "dynamic_resolution", "batch_size", "dynamic_crops", "action")
+
     def __init__(self, loss_fn, target, positive, unconditional, neutral, negative=None, settings=None) -> None:
-        if settings is None and isinstance(negative, PromptSettings):  # upstream 6-positional-argument form
-            settings, negative = negative, None
+        if settings is None and isinstance(negative, PromptSettings):
+            negative, settings = None, negative
         self.loss_fn = loss_fn
-        self.target = target
-        self.positive = positive
-        self.negative = negative if negative is not None else unconditional
-        self.unconditional = unconditional
-        self.neutral = neutral
-        self.guidance_scale = settings.guidance_scale
-        self.resolution = settings.resolution
-        self.dynamic_resolution = settings.dynamic_resolution
-        self.batch_size = settings.batch_size
-        self.dynamic_crops = settings.dynamic_crops
-        self.action = settings.action
+        self.target, self.positive, self.unconditional, self.neutral = target, positive, unconditional, neutral
+        self.negative = unconditional if negative is None else negative
+        for name in self._COPIED:
+            setattr(self, name, getattr(settings, name))
 
     def embeddings(self):
         return [self.target, self.positive, self.negative, self.unconditional, self.neutral]
 
-    def _erase(self, target_latents, positive_latents, neutral_latents, negative_latents):
+    def _guided(self, sign, target_latents, positive_latents, neutral_latents, negative_latents):
         return self.loss_fn(target_latents,
-                            neutral_latents - self.guidance_scale * (positive_latents - negative_latents))
+                            neutral_latents + (sign * self.guidance_scale) * (positive_latents - negative_latents))
 
-    def _enhance(self, target_latents, positive_latents, neutral_latents, negative_latents):
-        return self.loss_fn(target_latents,
-                            neutral_latents + self.guidance_scale * (positive_latents - negative_latents))
+    def _erase(self, **latents):
+        return self._guided(_ACTION_SIGN["erase"], **latents)
 
-    def loss(self, **kwargs):
-        if "unconditional_latents" in kwargs:  # upstream four-prompt keyword
-            kwargs["negative_latents"] = kwargs.pop("unconditional_latents")
-        if self.action == "erase":
-            return self._erase(**kwargs)
-        elif self.action == "enhance":
-            return self._enhance(**kwargs)
-        raise ValueError("action must be erase or enhance")
+    def _enhance(self, **latents):
+        return self._guided(_ACTION_SIGN["enhance"], **latents)
+
+    def loss(self, **latents):
+        """Keywords: target_latents, positive_latents, neutral_latents and negative_latents (or upstream's
+        unconditional_latents)."""
+        if "unconditional_latents" in latents:
+            latents["negative_latents"] = latents.pop("unconditional_latents")
+        if self.action not in _ACTION_SIGN:
+            raise ValueError("action must be erase or enhance")
+        return self._guided(_ACTION_SIGN[self.action], **latents)
 
 
-def load_prompts_from_yaml(path, attributes=[]):
-    with open(path, "r") as f:
-        prompts = yaml.safe_load(f)
-    if prompts is None or len(prompts) == 0:
+def load_prompts_from_yaml(path, attributes: Sequence[str] = ()):
+    """Reads prompts.yaml; with attributes, every entry is repeated once per attribute with the attribute prefixed to
+    each prompt it has (the reference prefixes `negative` unconditionally and KeyErrors on its own shipped
+    prompts.yaml, prompt_util.py:191 -- a missing key is simply skipped here)."""
+    with open(path, "r") as fh:
+        entries = yaml.safe_load(fh)
+    if not entries:
         raise ValueError("prompts file is empty")
-    if len(attributes) != 0:
-        newprompts = []
-        for i in range(len(prompts)):
-            for att in attributes:
-                copy_ = copy.deepcopy(prompts[i])
-                for key in ("target", "positive", "neutral", "negative", "unconditional"):
-                    if key in copy_:  # the reference indexes 'negative' unconditionally and KeyErrors on its own
-                        copy_[key] = att + " " + copy_[key]  # shipped prompts.yaml (prompt_util.py:191)
-                newprompts.append(copy_)
-    else:
-        newprompts = copy.deepcopy(prompts)
-    return [PromptSettings(**prompt) for prompt in newprompts]
+    if attributes:
+        entries = [{k: (f"{att} {v}" if k in _PROMPT_KEYS else v) for k, v in entry.items()}
+                   for entry in entries for att in attributes]
+    return [PromptSettings(**dict(entry)) for entry in entries]
