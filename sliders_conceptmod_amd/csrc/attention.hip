@@ -306,21 +306,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
   const auto rV = make_rsrc((const T*)p.V + (int64_t)b * p.Nk * p.ldv, (uint32_t)((int64_t)p.Nk * p.ldv * 2));
 
+  const auto rO = make_rsrc((const T*)p.O + (int64_t)b * p.Nq * p.ldo, (uint32_t)((int64_t)p.Nq * p.ldo * 2));
   typename TT<T>::v8 qf[NS], gf[NS];
+  // delta[q] = sum_d dO[q, d] O[q, d] is formed here from the dO fragments this lane holds anyway (one extra read of
+  // the O rows) and published for the dK / dV kernel that runs next -- no separate delta launch when dQ is wanted
+  float dpart = 0.f;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int d = 16 * s + 8 * h2;
     const bool ok = (q_idx < p.Nq) && (d < p.D);
-    Pack8<T> t, u;
+    Pack8<T> t, u, w;
     t.u = buf_load16(rQ, ok ? (uint32_t)(((int64_t)q_idx * p.ldq + col0 + d) * 2) : OOB);
     u.u = buf_load16(rG, ok ? (uint32_t)(((int64_t)q_idx * p.lddo + col0 + d) * 2) : OOB);
+    w.u = buf_load16(rO, ok ? (uint32_t)(((int64_t)q_idx * p.ldo + col0 + d) * 2) : OOB);
     qf[s] = t.v;
     gf[s] = u.v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dpart += to_f(u.e[j]) * to_f(w.e[j]);
   }
   const bool qok = q_idx < p.Nq;
   const int64_t stat = ((int64_t)b * p.H + head) * p.Nq + (qok ? q_idx : 0);
   const float lse2 = qok ? p.lse[stat] * LOG2E : INFINITY;
-  const float dlt = qok ? p.delta[stat] : 0.f;
+  const float dlt = dpart + __shfl_xor(dpart, 32);
+  if (qok && h2 == 0) p.delta[stat] = dlt;
   const float sl = p.scale * LOG2E;
 
   f32x16 dq[NB];
@@ -573,7 +581,7 @@ int fwd_t(const AttnParams& p, hipStream_t st) {
 
 template <typename T, int DP>
 int bwd_t(const AttnParams& p, hipStream_t st) {
-  {
+  if (!p.dQ) {  // dK / dV only: nobody else forms delta
     const int64_t total = (int64_t)p.B * p.H * p.Nq;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, st, p);
