@@ -302,7 +302,7 @@ static int gemm_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SMI_GEMM");
-    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : 0))))))))));
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : (!strcmp(e, "64w") ? 11 : 0)))))))))));
   }
   return mode;
 }
@@ -352,7 +352,8 @@ bool tune_enabled() {
   }
   return on == 1;
 }
-// candidate codes: 0 = heuristic, 1 = v2 128x128 (8 waves), 2 = v2 256x128, 4 = v2 128x160, 100 = v3 8-phase
+// candidate codes: 0 = heuristic, 1 = v2 128x128 (8 waves), 2 = v2 256x128, 4 = v2 128x160, 7 = v2 64x128,
+// 100 = v3 8-phase
 int launch_candidate(const GemmParams& p, int cand, hipStream_t stream) {
   if (cand == 100 && gemm3_supported(p)) return launch_gemm3(p, stream);  // (layout re-checked: the key is shape-only)
   if (cand == 0 || cand == 100) {
@@ -371,7 +372,7 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
   auto& cache = tune_cache();
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
-  int cands[5], nc = 0;
+  int cands[6], nc = 0;
   cands[nc++] = 0;
   const bool plain_conv = p.conv && p.stride == 1 && !p.upsample && !p.transposed;
   if (!p.conv || plain_conv) {
@@ -379,6 +380,7 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
     if ((int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 128) cands[nc++] = 2;
     if (p.N % 160 == 0 && (!p.geglu_out || p.N % 320 == 0)) cands[nc++] = 4;
     if (gemm3_supported(p) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) cands[nc++] = 100;
+    if (!p.conv && (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) <= 512) cands[nc++] = 7;  // 64 x 128 tiles for small grids
   }
   int best = 0;
   if (nc > 1) {
@@ -445,7 +447,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
       SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
                 "conv: inconsistent geometry");
     }
-    return launch_gemm2(p, gemm_mode() == 10 ? 6 : gemm_mode() == 9 ? 5 : gemm_mode() == 8 ? 4 : ((gemm_mode() == 4 || gemm_mode() >= 6) ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode())), stream);
+    return launch_gemm2(p, gemm_mode() == 11 ? 7 : gemm_mode() == 10 ? 6 : gemm_mode() == 9 ? 5 : gemm_mode() == 8 ? 4 : ((gemm_mode() == 4 || gemm_mode() >= 6) ? 0 : (gemm_mode() == 5 ? 3 : gemm_mode())), stream);
   }
   SMI_CHECK(p.K % 8 == 0 && p.N % 4 == 0, "gemm: K %% 8 and N %% 4 must be 0 (K=%d N=%d)", p.K, p.N);
   SMI_CHECK(p.ldc % 4 == 0, "gemm: ldc %% 4 != 0");

@@ -543,9 +543,11 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
   if (variant == 3) wm = 1;
   if (variant == 4 && ok160) { wm = 2; nl = 1; }
   if (variant == 5) { wm = 2; nl = 2; }
+  if (variant == 7 && !p.conv) { wm = 1; nl = 2; }  // 64 x 128 tile, 4 waves of 32 x 64: twice the tiles for small grids
 #define GO(TT_, CV, W_, NL_) return launch_t<TT_, CV, W_, NL_>(p, stream)
 #define PICK(TT_, CV)                            \
   do {                                           \
+    if (nl == 2 && wm == 1 && !CV) GO(TT_, false, 1, 2); \
     if (nl == 2) GO(TT_, CV, 2, 2);              \
     if (nl) GO(TT_, CV, 2, 1);                   \
     if (wm == 4) GO(TT_, CV, 4, 0);              \
