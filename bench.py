@@ -39,9 +39,11 @@ CONFIGS = {
 def pmc_traffic(config):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py); None
     when no such pass exists for this configuration."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config}.json")
-    if not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{config}.json")))
+    if not paths:
         return None
+    path = paths[-1]  # the latest round's passes (file names sort by round tag)
     rows = [v for k, v in json.load(open(path)).items() if "gemm_glds_kernel" in k or "gemm_8ph_kernel" in k]
     n = sum(v["launches"] for v in rows)
     return (sum(v["total_fetch_bytes"] + v["total_write_bytes"] for v in rows) / n) if n else None
@@ -87,42 +89,80 @@ def algorithmic_step_flops(engine_profile):
     return sum(v["flops"] for v in engine_profile.values())
 
 
-def cpu_baseline(model, rank_, step_flops, seconds_budget=25.0):
-    """Times the CPU oracle (a port: oracle/unet_ref.py) on this box's host cores on a bounded sample of the same
-    workload: UNet forwards at reduced latent size, converted to steps/s by the algorithmic FLOP ratio."""
+def host_cpu_info():
+    """(model name, physical cores, logical CPUs this process may run on) from /proc/cpuinfo and the affinity mask."""
+    name, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and name == "unknown":
+                name = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return name, len(cores) or (os.cpu_count() or 1), usable
+
+
+def cpu_baseline(model, lrank, step_flops, gpu_res, seconds_budget=45.0):
+    """The CPU oracle (kind "port": oracle/slider_ref.py + oracle/unet_ref.py, fp32 PyTorch on the host cores) timed on
+    ONE WHOLE STEP in the reference's order: 3 frozen forwards + 1 adapted forward + guidance
+    loss + backward + clip + AdamW at UNet batch 2B, B = 1, at a reduced resolution (SD-XL: 512^2 px; 256^2 if a short
+    forward probe says 512^2 would not fit the time budget), then scaled to the benchmarked configuration by the
+    algorithmic FLOP ratio -- stated as an extrapolation in `sample`."""
+    from oracle import sched_ref as OS
+    from oracle import slider_ref as R
     from oracle import unet_ref as OU
+    cpu_name, phys, usable = host_cpu_info()
     # the GPU box grants a 16-core share per GPU whatever os.cpu_count() says; oversubscribing it is far slower
-    ncores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(ncores)
+    nthreads = max(1, min(16, usable))
+    torch.set_num_threads(nthreads)
     ocfg = {"sdxl": OU.sdxl_config, "sd1x": OU.sd1x_config, "tiny_sdxl": OU.tiny_sdxl_config}[model]()
+    xl = ocfg.addition_embed_type == "text_time"
+    ou = OU.UNet2DConditionModel(ocfg)
     with torch.no_grad():
-        ou = OU.UNet2DConditionModel(ocfg)
         for p in ou.parameters():  # cheap deterministic fill: timing does not depend on the values
             p.uniform_(-0.02, 0.02)
-        ou.eval()
-        lat = 32 if model != "tiny_sdxl" else 16
-        n = 2
-        x = torch.randn(n, 4, lat, lat)
-        ctx = torch.randn(n, 77, ocfg.cross_attention_dim)
-        add = None
-        if ocfg.addition_embed_type == "text_time":
-            pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
-            add = {"text_embeds": torch.randn(n, pdim), "time_ids": torch.tensor([[256.0, 256, 0, 0, 256, 256]] * n)}
-        # FLOPs of the sample, counted by hooks on Linear / Conv2d (+ attention analytically)
-        flops = [0.0]
+    ou.requires_grad_(False).eval()
+    net = R.LoRANetworkRef(ou, lrank, 1.0, 1.0, "noxattn")
+    with torch.no_grad():
+        for l in net.unet_loras:
+            l.lora_up.weight.normal_(0, 1e-2)
+    params = [p for l in net.unet_loras for p in l.parameters()]
+    keys = ["target", "positive", "neutral", "unconditional"] + (["negative"] if xl else [])
+    emb = {k: torch.randn(1, 77, ocfg.cross_attention_dim) for k in keys}
+    xlc = None
+    if xl:
+        pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
+        xlc = {"pooled": {k: torch.randn(1, pdim) for k in keys}}
+    sched = OS.create_noise_scheduler_ref("euler_a" if xl else "ddim")
+    sched.set_timesteps(1000)
+    t = sched.timesteps[500]
 
-        def lin_hook(m, inp, out):
-            flops[0] += 2.0 * out.numel() * m.in_features
+    # FLOPs of what is timed, counted by hooks on Linear / Conv2d (+ attention analytically): forward hooks count the
+    # forward; the backward is counted as the engine counts it (dX only, attention x2) via the same ratio Bk/F
+    flops = [0.0]
 
-        def conv_hook(m, inp, out):
-            flops[0] += 2.0 * out.numel() * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+    def lin_hook(m, inp, out):
+        flops[0] += 2.0 * out.numel() * m.in_features
 
-        def attn_hook(m, args, kwargs, out):
-            xq = args[0]
-            ctx_ = kwargs.get("context", args[1] if len(args) > 1 else None)
-            nk = xq.shape[1] if ctx_ is None else ctx_.shape[1]
-            flops[0] += 4.0 * xq.shape[0] * xq.shape[1] * nk * m.to_q.out_features
+    def conv_hook(m, inp, out):
+        flops[0] += 2.0 * out.numel() * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
 
+    def attn_hook(m, args, kwargs, out):
+        xq = args[0]
+        ctx_ = kwargs.get("context", args[1] if len(args) > 1 else None)
+        nk = xq.shape[1] if ctx_ is None else ctx_.shape[1]
+        flops[0] += 4.0 * xq.shape[0] * xq.shape[1] * nk * m.to_q.out_features
+
+    def hooked_forward_flops(lat):
         hs = []
         for m in ou.modules():
             if isinstance(m, torch.nn.Linear):
@@ -131,25 +171,69 @@ def cpu_baseline(model, rank_, step_flops, seconds_budget=25.0):
                 hs.append(m.register_forward_hook(conv_hook))
             elif m.__class__.__name__ == "Attention":
                 hs.append(m.register_forward_hook(attn_hook, with_kwargs=True))
-        ou(x, 499.0, ctx, add)  # warm-up + FLOP count
+        flops[0] = 0.0
+        x = torch.randn(2, 4, lat, lat)
+        add = None
+        if xl:
+            add = {"text_embeds": torch.randn(2, pdim), "time_ids": torch.tensor([[8.0 * lat] * 2 + [0, 0] + [8.0 * lat] * 2] * 2)}
+        t0 = time.time()
+        with torch.no_grad():
+            ou(x, 499.0, torch.randn(2, 77, ocfg.cross_attention_dim), add)
+        dt = time.time() - t0
         for h in hs:
             h.remove()
-        sample_flops = flops[0]
-        t0 = time.time()
-        reps = 0
-        while True:
-            ou(x, 499.0, ctx, add)
-            reps += 1
-            if time.time() - t0 > seconds_budget or reps >= 8:
-                break
-        dt = (time.time() - t0) / reps
-    cpu_flops_per_s = sample_flops / dt
+        return flops[0], dt
+
+    # probe (also the warm-up): one doubled-batch forward at 32x32 latents -> forward TFLOP/s of this host
+    probe_lat = 16 if model == "tiny_sdxl" else 32
+    hooked_forward_flops(probe_lat)
+    pf, pdt = hooked_forward_flops(probe_lat)
+    rate = pf / pdt
+    lat = probe_lat
+    for cand in ([64] if model != "tiny_sdxl" else []):
+        f_c = pf * (cand / probe_lat) ** 2 * 1.15  # attention grows faster than the pixel count
+        if 5.3 * f_c / rate <= seconds_budget:     # step ~ 4 forwards + backward (~1.3 forward)
+            lat = cand
+    fwd_flops, _ = hooked_forward_flops(lat)        # FLOPs of ONE forward of the doubled batch (2 samples)
+    if xl:
+        xlc["time_ids"] = torch.tensor([[8.0 * lat, 8.0 * lat, 0.0, 0.0, 8.0 * lat, 8.0 * lat]])
+    denoised = torch.randn(1, 4, lat, lat)
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    t0 = time.time()
+    loss, _ = R.slider_step(ou, net, sched, denoised, t, emb, 1, "enhance", 4.0, cfg_scale=1.0, xl=xlc)
+    t_fwd = time.time() - t0
+    loss.backward()
+    t_bwd = time.time() - t0 - t_fwd
+    if xl:
+        R.clip_grad_norm_(params, 0.2)
+    with torch.no_grad():
+        for p, mm, vv in zip(params, m, v):
+            R.adamw_step_(p, p.grad, mm, vv, 1, 1e-4, weight_decay=1e-6)
+    dt = time.time() - t0
+    # algorithmic FLOPs of the timed step with the engine's counting rule: 4 forwards + backward (dX only; the
+    # benchmarked step's ratio backward/forward is taken from its own profile: step = 4F + Bk)
+    sample_step_flops = fwd_flops * (4.0 + BWD_OVER_FWD.get(model, 1.12))
+    steps_per_s_sample = 1.0 / dt
     return {
-        "value": cpu_flops_per_s / step_flops, "unit": "steps/s", "cores": ncores, "kind": "port",
-        "sample": f"oracle/unet_ref.py {model} UNet forward, fp32, batch {n} at {lat}x{lat} latents, {reps} reps, "
-                  f"{dt:.2f} s each = {cpu_flops_per_s / 1e12:.3f} TFLOP/s on {ncores} threads; steps/s extrapolated by "
-                  f"algorithmic FLOPs ({sample_flops / 1e12:.3f} TFLOP per sample vs {step_flops / 1e12:.1f} per step)",
+        "value": steps_per_s_sample * sample_step_flops / step_flops, "unit": "steps/s", "cores": nthreads,
+        "kind": "port",
+        "host": {"cpu": cpu_name, "physical_cores": phys, "usable_logical_cpus": usable, "threads_used": nthreads},
+        "measured": {"steps_per_s": steps_per_s_sample, "seconds_per_step": dt, "forward_s": t_fwd, "backward_s": t_bwd,
+                     "resolution": lat * 8, "batch": 1, "unet_batch": 2,
+                     "tflop_per_step": sample_step_flops / 1e12, "tflops": sample_step_flops / dt / 1e12},
+        "sample": f"ONE whole oracle step (oracle/slider_ref.slider_step: 3 frozen + 1 adapted UNet forward, loss, "
+                  f"backward, clip, AdamW; fp32, {model}, rank {lrank}) at {lat * 8}x{lat * 8} px, B = 1 (UNet batch 2): "
+                  f"{dt:.1f} s = {sample_step_flops / 1e12:.2f} TFLOP at {sample_step_flops / dt / 1e12:.3f} TFLOP/s on "
+                  f"{nthreads} threads of '{cpu_name}' ({phys} physical cores on the box, {usable} usable); `value` is "
+                  f"EXTRAPOLATED to the benchmarked {gpu_res}x{gpu_res} step by the algorithmic FLOP ratio "
+                  f"({step_flops / 1e12:.1f} TFLOP per step)",
     }
+
+
+# backward / forward algorithmic FLOPs (dX only, attention counted twice): SD-XL 7.545 / 6.761, SD-1.x 0.929 / 0.803
+# (SURVEY.md section 8d); the sample's FLOPs are counted as forward x (4 + this), the same rule bench's profile uses
+BWD_OVER_FWD = {"sdxl": 7.545 / 6.761, "sd1x": 0.929 / 0.803}
 
 
 def log(msg):
@@ -257,10 +341,27 @@ def main():
         loss = step.train_step(denoised, timestep, cond, "enhance", 4.0)
     sync()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
+    allreduce_us = None
     if world > 1:
         te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(te.item())
+        tl = [torch.zeros_like(te) for _ in range(world)]
+        torch.distributed.all_gather(tl, te)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in tl]
+        elapsed = max(float(x.item()) for x in tl)  # MAX over ranks
+        # the step's one collective on its own: HIP events around the flat fp32 LoRA-gradient all-reduce
+        from sliders_conceptmod_amd import parallel
+        buf = step.grad.clone()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        parallel.allreduce_mean_(buf)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        ev[0].record()
+        for _ in range(10):
+            parallel.allreduce_mean_(buf)
+        ev[1].record()
+        torch.cuda.synchronize()
+        allreduce_us = ev[0].elapsed_time(ev[1]) * 1e3 / 10
     loss_val = float(loss.item())
     if rank == 0:
         log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step; profiling one step")
@@ -310,6 +411,10 @@ def main():
                        "guidance_passes": "4 separate UNet calls" if args.separate_passes else
                        "1 batched UNet call (3 frozen + 1 adapted sub-batches)"},
             "samples_per_s": args.steps * B * world / elapsed,
+            "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            "allreduce": None if allreduce_us is None else {
+                "us": allreduce_us, "bytes": int(step.grad.numel() * 4),
+                "what": "flat fp32 LoRA gradient, all-reduce(sum) + divide, on the compute stream (RCCL)"},
             "loss": loss_val,
             "preroll": {"forwards": n_pre, "ms": preroll_ms, "unet_batch": 2 * B,
                         "note": "no-grad diffusion(_xl) pre-roll at its mean length, adaptor on; NOT part of `value`",
@@ -336,7 +441,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log("GPU part done; timing the CPU oracle sample: " + json.dumps({k: out[k] for k in ("value", "ms_per_step")}))
             try:
-                out["cpu_baseline"] = cpu_baseline(model, rank, step_flops)
+                out["cpu_baseline"] = cpu_baseline(model, lrank, step_flops, res)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

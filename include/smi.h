@@ -91,6 +91,23 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
                size_t workspace_bytes, void* stream, smi_engine** out);
 void smi_destroy(smi_engine* e);
 
+/* Engine lifetime across shapes.  The packed weights do not depend on the batch or the latent size; only the two
+ * activation arenas do.  smi_workspace_bytes == smi_weights_bytes + smi_arena_bytes (+ alignment slack).
+ * smi_replan switches a live engine to another (batch, batch_adapted, h, w, ctx_len) WITHOUT re-packing any weight:
+ * `arena` is a caller-owned buffer of >= smi_arena_bytes(...) bytes that must outlive its use (NULL: reuse the arena
+ * region of the creation workspace, if large enough).  It invalidates a saved forward (smi_unet_backward then fails
+ * with -4).  This is what the reference's `dynamic_resolution` (a random bucket every step, train_util.py:1085-1097;
+ * train_lora.py:172-178) needs: keep one arena per bucket and replan between them. */
+int smi_weights_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, size_t* bytes);
+int smi_arena_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int batch_adapted,
+                    int h, int w, int ctx_len, size_t* bytes);
+int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ctx_len, void* arena,
+               size_t arena_bytes);
+/* out[0] = weight-packing kernel launches since creation, out[1] = replans, out[2] = generation number of the saved
+ * forward whose tape is live (0: none; each save_for_backward forward gets a new number -- callers keep it next to the
+ * output they will differentiate and compare before smi_unet_backward), out[3] = bytes of the packed-weight region. */
+int smi_engine_stats(const smi_engine* e, int64_t out[4]);
+
 /* eps = unet(sample, t, ctx[, text_embeds, time_ids]).sample           (train_util.py:290-294, 471-476)
  *   sample      f32 [n, 4, h, w]  (NCHW, already scale_model_input-ed)
  *   ctx         T   [n, ctx_len, cross_attention_dim]

@@ -52,6 +52,11 @@ _SIGS = {
     "smi_unet_forward_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "smi_destroy": (None, [C.c_void_p]),
+    "smi_weights_bytes": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(LoraSiteC), C.c_int, C.POINTER(C.c_size_t)]),
+    "smi_arena_bytes": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(LoraSiteC), C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "smi_replan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "smi_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "smi_unet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "smi_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -166,8 +171,25 @@ def workspace_bytes(cfg_c: UNetConfigC, sites: Sequence[dict], batch: int, h: in
     return out.value
 
 
+def arena_bytes(cfg_c: UNetConfigC, sites: Sequence[dict], batch: int, h: int, w: int, ctx_len: int,
+                batch_adapted: Optional[int] = None) -> int:
+    arr, _keep = make_sites(sites)
+    out = C.c_size_t(0)
+    ba = batch if batch_adapted is None else batch_adapted
+    check(lib().smi_arena_bytes(C.byref(cfg_c), arr, len(sites), batch, ba, h, w, ctx_len, C.byref(out)),
+          "smi_arena_bytes")
+    return out.value
+
+
 class Engine:
-    """Owns one smi_engine plus the torch tensors backing its workspace."""
+    """Owns one smi_engine plus the torch tensors backing its workspace.
+
+    The packed weights are shape-independent; `plan(batch, batch_adapted, h, w, ctx_len)` switches the engine to
+    another shape by pointing it at another activation arena (smi_replan) -- no weight is re-packed and no GEMM tile is
+    re-tuned for shapes already seen.  A small LRU of arenas keeps the `dynamic_resolution` buckets
+    (T/train_util.py:1085-1097) resident; MAX_PLANS bounds it."""
+
+    MAX_PLANS = 4
 
     def __init__(self, cfg, dtype: torch.dtype, state: dict, sites: Sequence[dict], batch: int, h: int, w: int,
                  ctx_len: int, device, batch_adapted: Optional[int] = None):
@@ -200,6 +222,35 @@ class Engine:
                   "smi_create")
         self.handle = handle
         self.stream = torch.cuda.current_stream().cuda_stream
+        self._home = (batch, self.batch_adapted, h, w, ctx_len)  # the shape the creation workspace was sized for
+        self._plans = {}                                         # shape -> arena tensor (LRU, most recent last)
+
+    def plan(self, batch: int, batch_adapted: int, h: int, w: int, ctx_len: int):
+        """Make (batch, batch_adapted, h, w, ctx_len) the engine's current shape (no-op when it already is)."""
+        cur = (self.batch, self.batch_adapted, self.h, self.w, self.ctx_len)
+        want = (batch, batch_adapted, h, w, ctx_len)
+        if want == cur:
+            return
+        arena = None
+        if want != self._home:
+            arena = self._plans.pop(want, None)
+            if arena is None:
+                nbytes = arena_bytes(self.cfg_c, self.sites, batch, h, w, ctx_len, batch_adapted)
+                while len(self._plans) >= self.MAX_PLANS:
+                    self._plans.pop(next(iter(self._plans)))
+                arena = torch.empty(nbytes, dtype=torch.uint8, device=self.workspace.device)
+            self._plans[want] = arena
+        check(lib().smi_replan(self.handle, batch, batch_adapted, h, w, ctx_len, ptr(arena),
+                               0 if arena is None else arena.numel()), "smi_replan")
+        self.batch, self.batch_adapted, self.h, self.w, self.ctx_len = want
+
+    def stats(self) -> dict:
+        out = (C.c_int64 * 4)()
+        check(lib().smi_engine_stats(self.handle, out), "smi_engine_stats")
+        return {"pack_launches": out[0], "replans": out[1], "tape_generation": out[2], "weights_bytes": out[3]}
+
+    def tape_generation(self) -> int:
+        return self.stats()["tape_generation"] if self.handle else 0
 
     def forward(self, sample: torch.Tensor, timestep: float, ctx: torch.Tensor, text_embeds, time_ids, lora_down,
                 lora_up, multiplier: float, save: bool, n_adapted: Optional[int] = None) -> torch.Tensor:

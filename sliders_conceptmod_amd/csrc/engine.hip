@@ -221,6 +221,8 @@ struct smi_engine {
   // workspace layout
   char* ws = nullptr;
   size_t ws_bytes = 0;
+  char* arena_home = nullptr;  // the arena region inside the creation workspace (smi_replan with arena == NULL)
+  size_t arena_home_bytes = 0;
   Arena wpack;     // packed weights + persistent small buffers
   Arena arena[2];  // 0: no-grad passes, 1: differentiated pass + backward
   Arena* cur = nullptr;
@@ -255,6 +257,11 @@ struct smi_engine {
   std::vector<std::function<void()>> tape;
   bool saving = false;
   bool tape_valid = false;
+  // every saved forward gets a generation number; the caller keeps it with the output it will differentiate and
+  // smi_unet_backward_checked refuses a stale one (a later saved forward, a replan or a backward dropped the tape)
+  uint64_t tape_gen = 0;
+  int64_t pack_launches = 0;  // weight-packing kernels launched so far (creation only: a replan must not add any)
+  int64_t replans = 0;
   const float* lora_down = nullptr;  // parameters of the forward in flight
   const float* lora_up = nullptr;
   const float* bw_down = nullptr;    // parameters of the saved (differentiated) forward, used by its backward
@@ -420,6 +427,7 @@ struct smi_engine {
   void transpose_into(const void* src, void* dst, int R, int C, int ldd, int col0) {
     if (dry || err || !src) return;
     const int grid = ((R + 63) / 64) * ((C + 63) / 64);
+    ++pack_launches;
     if (dtype == DT_F16)
       hipLaunchKernelGGL(pack_transpose_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, R, C, ldd, col0);
     else
@@ -431,6 +439,7 @@ struct smi_engine {
     else (void)hipMemsetAsync(dst, 0, (size_t)(mode == 0 ? Cout : Cin) * 9 * pad * esz(), stream);
     const int64_t total = (int64_t)Cout * Cin * 9;
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    ++pack_launches;
     if (dtype == DT_F16)
       hipLaunchKernelGGL(pack_conv_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, Cout, Cin, mode, pad);
     else
@@ -1236,6 +1245,7 @@ struct smi_engine {
     if (save) {
       tape.clear();
       tape_valid = false;
+      ++tape_gen;
     }
     tens = &tens_[save ? 1 : 0];
     tens->clear();
@@ -1405,7 +1415,11 @@ struct smi_engine {
     const int n = bw_n_ad, HW = lat_h * lat_w;  // d_eps covers the adapted samples only
     n_ad = bw_n_ad;
     Ten* y = out_ten;
-    if (!y->ng) return 0;  // adaptor off: nothing depends on the LoRA parameters
+    if (!y->ng) {  // adaptor off: nothing depends on the LoRA parameters
+      tape.clear();
+      tape_valid = false;
+      return 0;
+    }
     const int64_t cnt = (int64_t)n * cfg.out_channels * HW;
     RUN(launch_grad_scale(d_eps, cnt, gscale, stream));
     y->g = alloc_t(MA(y), 64);
@@ -1519,6 +1533,8 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
   e->arena[0].cap = r[1];
   e->arena[1].base = base + r[0] + r[1];
   e->arena[1].cap = r[2];
+  e->arena_home = base + r[0];
+  e->arena_home_bytes = (size_t)((char*)workspace + workspace_bytes - e->arena_home);
   e->build();
   if (!e->err) (void)hipStreamSynchronize(e->stream);
   if (e->err || hipGetLastError() != hipSuccess) {
@@ -1552,6 +1568,66 @@ void smi_destroy(smi_engine* e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   delete e;
+}
+
+int smi_weights_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, size_t* bytes) {
+  if (check_cfg(cfg)) return -1;
+  SMI_CHECK(bytes != nullptr, "bad arguments");
+  size_t r[3];
+  if (plan(cfg, sites, n_sites, 1, 1, 8, 8, 8, r)) return -1;  // the packed region does not depend on the shape
+  *bytes = r[0] + 4096;
+  return 0;
+}
+
+int smi_arena_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int batch_adapted,
+                    int h, int w, int ctx_len, size_t* bytes) {
+  if (check_cfg(cfg)) return -1;
+  SMI_CHECK(bytes && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
+            "bad arguments");
+  size_t r[3];
+  if (plan(cfg, sites, n_sites, batch, batch_adapted, h, w, ctx_len, r)) return -1;
+  *bytes = r[1] + r[2] + 2 * 4096;
+  return 0;
+}
+
+int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ctx_len, void* arena,
+               size_t arena_bytes) {
+  SMI_CHECK(e && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
+            "bad arguments");
+  size_t r[3];
+  if (plan(&e->cfg, e->sites.data(), (int)e->sites.size(), batch, batch_adapted, h, w, ctx_len, r)) return -1;
+  char* base = arena ? (char*)align_up((size_t)arena, 4096) : e->arena_home;
+  const size_t have = arena ? (size_t)((char*)arena + arena_bytes - base) : e->arena_home_bytes;
+  SMI_CHECK(r[1] + r[2] <= have, "arena too small for batch %d (%d adapted), %dx%d latents: need %zu bytes, got %zu", batch,
+            batch_adapted, h, w, r[1] + r[2] + 2 * 4096, arena ? arena_bytes : e->arena_home_bytes);
+  e->join_side();
+  e->max_n = batch;
+  e->max_n_ad = batch_adapted;
+  e->lat_h = h;
+  e->lat_w = w;
+  e->ctx_len = ctx_len;
+  e->arena[0] = Arena();
+  e->arena[1] = Arena();
+  e->arena[0].base = base;
+  e->arena[0].cap = r[1];
+  e->arena[1].base = base + r[1];
+  e->arena[1].cap = r[2];
+  e->tape.clear();  // the saved activations lived in the old arena
+  e->tape_valid = false;
+  e->tens_[0].clear();
+  e->tens_[1].clear();
+  e->out_ten = nullptr;
+  ++e->replans;
+  return 0;
+}
+
+int smi_engine_stats(const smi_engine* e, int64_t out[4]) {
+  SMI_CHECK(e && out, "NULL argument");
+  out[0] = e->pack_launches;
+  out[1] = e->replans;
+  out[2] = e->tape_valid ? (int64_t)e->tape_gen : 0;
+  out[3] = (int64_t)e->wpack.peak;
+  return 0;
 }
 
 int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* sample, float timestep, const void* ctx,

@@ -115,7 +115,12 @@ class EulerAncestralDiscreteScheduler:
         sigma_up = (sigma_to ** 2 * (sigma ** 2 - sigma_to ** 2) / sigma ** 2) ** 0.5
         sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
         # host torch RNG (global generator) keeps the draw order of the reference run: SURVEY.md section 7 "RNG parity"
-        noise = torch.randn(model_output.shape, dtype=torch.float32, generator=generator)
+        # under data parallelism (`dp_shard = (rank, world)`, set by the trainers) the GLOBAL batch's noise is drawn and
+        # this rank's rows are taken, so W ranks consume the control RNG like one rank at the global batch
+        rank, world = getattr(self, "dp_shard", (0, 1))
+        from .parallel import shard_noise
+        noise = shard_noise(lambda shp: torch.randn(shp, dtype=torch.float32, generator=generator),
+                            tuple(model_output.shape), rank, world)
         # prev = x + eps * (sigma_down - sigma) + noise * sigma_up       (derivative = eps for epsilon prediction)
         return _StepOutput(_affine(sample, model_output, noise, 1.0, sigma_down - sigma, sigma_up))
 

@@ -4,6 +4,7 @@ Contract: every rank seeds the control RNG identically, d
 takes its slice; after backward the flat fp32 LoRA gradient is all-reduced (sum) and divided by the world size
 BEFORE any clipping, so W ranks at global batch B equal one rank at batch B up to reduction order
 (MSE mean over the global batch == mean over ranks of the per-shard means, shards being equal-sized)."""
+import random
 from typing import Optional
 
 import torch
@@ -30,3 +31,39 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(world)
     return flat
+
+
+def sync_control_rng(group=None, device=None) -> int:
+    """Makes the contract above true: rank 0 draws a seed, broadcasts it, and every rank seeds torch's global
+    generator and `random` with it.  Must run BEFORE the LoRANetwork is built (its kaiming init draws from the global
+    generator) and before the training loop (pair index, timesteps_to, resolution bucket, latents, Euler-a noise).
+    Single-rank runs are left untouched (the reference does not seed, T/train_lora.py:32-100)."""
+    rank, world = world_info(group)
+    if world == 1:
+        return torch.initial_seed()
+    seed = torch.tensor([torch.initial_seed() % (2 ** 62)], dtype=torch.int64)
+    if device is not None and dist.get_backend(group) == "nccl":
+        seed = seed.to(device)
+    dist.broadcast(seed, src=0, group=group)
+    s = int(seed.item())
+    torch.manual_seed(s)
+    random.seed(s)
+    return s
+
+
+def broadcast_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Rank 0's copy of a parameter buffer to every rank (belt and braces after sync_control_rng: replicas start
+    bit-equal even if a caller built the network before seeding)."""
+    _, world = world_info(group)
+    if world > 1:
+        dist.broadcast(t, src=0, group=group)
+    return t
+
+
+def shard_noise(draw, shape, rank: int, world: int):
+    """Draws the noise of the GLOBAL batch (`draw(global_shape)` on the shared control RNG) and returns this rank's
+    rows, so W ranks consume the RNG exactly like one rank at the global batch."""
+    if world == 1:
+        return draw(tuple(shape))
+    g = (shape[0] * world,) + tuple(shape[1:])
+    return draw(g)[rank * shape[0]:(rank + 1) * shape[0]]

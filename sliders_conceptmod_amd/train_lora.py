@@ -43,12 +43,17 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
     tokenizer, text_encoder, unet, noise_scheduler = models or model_util.load_models(
         config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler,
         v2=config.pretrained_model.v2, v_pred=config.pretrained_model.v_pred)
+    # data parallelism: one control RNG for all ranks, seeded BEFORE the adaptor init draws from it (parallel.py)
+    rank, world = parallel.world_info()
+    parallel.sync_control_rng(device=device)
+    noise_scheduler.dp_shard = (rank, world)
     unet.to(device, dtype=weight_dtype)
     unet.enable_xformers_memory_efficient_attention()
     unet.requires_grad_(False)
     unet.eval()
     network = LoRANetwork(unet, rank=config.network.rank, multiplier=1.0, alpha=config.network.alpha,
                           train_method=config.network.training_method).to(device, dtype=weight_dtype)
+    parallel.broadcast_(network.flat.data)
     optimizer_module = train_util.get_optimizer(config.train.optimizer)
     optimizer_kwargs = {}
     if config.train.optimizer_args is not None and len(config.train.optimizer_args) > 0:
@@ -72,8 +77,6 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
                                                  settings=settings))
     del tokenizer, text_encoder
 
-    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     pbar = tqdm(range(config.train.iterations), disable=rank != 0)
     loss = None
     for i in pbar:

@@ -60,11 +60,14 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     weight_dtype = config_util.parse_precision(config.train.precision)
     tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
         config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=True)
+    rank_, world = parallel.world_info()
+    parallel.sync_control_rng(device=device)  # one control RNG (torch + random) for all ranks, before the adaptor init
     unet.to(device, dtype=weight_dtype)
     unet.requires_grad_(False)
     unet.eval()
     network = LoRANetwork(unet, rank=rank, multiplier=1.0, alpha=config.network.alpha,
                           train_method=config.network.training_method).to(device, dtype=weight_dtype)
+    parallel.broadcast_(network.flat.data)
     optimizer = train_util.get_optimizer(config.train.optimizer)(network.prepare_optimizer_params(),
                                                                  lr=config.train.lr)
     lr_scheduler = train_util.get_lr_scheduler(config.train.lr_scheduler, optimizer,
@@ -73,18 +76,26 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     with torch.no_grad():
         pos = encode_xl(text_encoders, tokenizers, settings.positive, device, weight_dtype)
         neu = encode_xl(text_encoders, tokenizers, settings.neutral, device, weight_dtype)
-    scales = sorted(float(s) for s in scales)
-    folders = [f for _, f in sorted(zip([float(s) for s in scales], folders))] if len(folders) == len(scales) else folders
-    names = sorted(os.listdir(os.path.join(folder_main, folders[0])))
-    rank_, world = parallel.world_info()
+    # folder <-> scale pairing by ORIGINAL index, as the reference does (folders[scales == s][0],
+    # I/train_lora-scale-xl.py:213-214); a length mismatch raises as there (:452-453)
+    if len(scales) != len(folders):
+        raise Exception("the number of folders need to match the number of scales")
+    scales = [float(s) for s in scales]
+    folder_of = {}
+    for s, f in zip(scales, folders):
+        folder_of.setdefault(s, f)
+    for s in scales:
+        if -s not in folder_of:
+            raise ValueError(f"scale {s:g} has no counterpart {-s:g} in --scales: the two-sided step needs both")
+    names = sorted(os.listdir(os.path.join(folder_main, folder_of[scales[0]])))
     save_path = Path(config.save.path)
+    save_dtype = config_util.parse_precision(config.train.precision)
     for i in tqdm(range(config.train.iterations), disable=rank_ != 0):
         noise_scheduler.set_timesteps(config.train.max_denoising_steps, device=device)
         optimizer.zero_grad()
         timesteps_to = torch.randint(1, config.train.max_denoising_steps - 1, (1,)).item()
         scale_to_look = abs(random.choice(scales))
-        f_low = folders[scales.index(-scale_to_look)]
-        f_high = folders[scales.index(scale_to_look)]
+        f_low, f_high = folder_of[-scale_to_look], folder_of[scale_to_look]
         name = names[(random.randint(0, len(names) - 1) + rank_) % len(names)]  # ranks take different pairs
         lat_low = _load_latent(os.path.join(folder_main, f_low, name)).unsqueeze(0).float()
         lat_high = _load_latent(os.path.join(folder_main, f_high, name)).unsqueeze(0).float()
@@ -105,10 +116,12 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
         parallel.allreduce_mean_(network.flat.grad)
         optimizer.step()
         lr_scheduler.step()
+        if rank_ == 0 and i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1:
+            save_path.mkdir(parents=True, exist_ok=True)  # I/train_lora-scale-xl.py:402-412
+            network.save_weights(save_path / f"{config.save.name}_{i}steps.pt", dtype=save_dtype)
     if rank_ == 0:
         save_path.mkdir(parents=True, exist_ok=True)
-        network.save_weights(save_path / f"{config.save.name}_last.safetensors",
-                             dtype=config_util.parse_precision(config.train.precision))
+        network.save_weights(save_path / f"{config.save.name}_last.pt", dtype=save_dtype)
     return network
 
 

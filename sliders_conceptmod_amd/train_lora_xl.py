@@ -35,7 +35,10 @@ def encode_xl(text_encoder, tokenizer, prompt, device, dtype) -> PromptEmbedsXL:
 
 
 def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft_type="lora", rank=4, save_file=True,
-          models=None, fused_step=False):
+          models=None, fused_step=False, optimizer_kwargs=None):
+    """`optimizer_kwargs` (not in the reference signature) overrides keyword arguments of the hard-coded AdamW
+    (train_lora_xl.py:104), e.g. {"eps": 1e-3} for the element-wise trajectory parity test; the per-step losses of the
+    run are left in `network.training_losses`."""
     if peft_type != "lora":
         raise NotImplementedError("--peft_type dora (conceptmod/textsliders/dora.py) is a 'next' row; only lora is built")
     save_path = Path(config.save.path)
@@ -44,13 +47,20 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
     guidance_scale = config.train.cfg
     tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
         config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=True)
+    # data parallelism: one control RNG for all ranks, seeded BEFORE the adaptor init draws from it (parallel.py)
+    rank_, world = parallel.world_info()
+    parallel.sync_control_rng(device=device)
+    noise_scheduler.dp_shard = (rank_, world)
     unet.to(device, dtype=weight_dtype)
     unet.requires_grad_(False)
     unet.eval()
     network = LoRANetwork(unet, rank=rank, multiplier=1.0, delimiter="_", target_replace=["Attention"],
                           prefix="lora_unet", train_method=config.network.training_method).to(device,
                                                                                               dtype=weight_dtype)
-    optimizer = torch.optim.AdamW(network.parameters(), lr=1e-4, weight_decay=1e-6)
+    parallel.broadcast_(network.flat.data)
+    okw = dict(lr=1e-4, weight_decay=1e-6)
+    okw.update(optimizer_kwargs or {})
+    optimizer = torch.optim.AdamW(network.parameters(), **okw)
     lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=50, eta_min=1e-6)
     criteria = torch.nn.MSELoss()
 
@@ -68,13 +78,14 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
                                                  settings))
     del tokenizers, text_encoders
 
-    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-    rank_ = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     stepper = None
     if fused_step:
         from .step import SliderStep
-        stepper = SliderStep(unet, network, noise_scheduler, lr=1e-4, weight_decay=1e-6, max_grad_norm=0.2,
+        stepper = SliderStep(unet, network, noise_scheduler, lr=okw["lr"], weight_decay=okw["weight_decay"],
+                             eps=okw.get("eps", 1e-8), betas=okw.get("betas", (0.9, 0.999)), max_grad_norm=0.2,
                              cfg_scale=guidance_scale)
+    cond_cache = {}  # fused path: conditioning tensors per (prompt pair, batch, size); rebuilt only with dynamic crops
+    network.training_losses = []
     pbar = tqdm(range(config.train.iterations), disable=rank_ != 0)
     for i in pbar:
         with torch.no_grad():
@@ -122,7 +133,10 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
             emb = {k: getattr(prompt_pair, k).text_embeds for k in
                    ("target", "positive", "neutral", "unconditional", "negative")}
             pooled = {k: getattr(prompt_pair, k).pooled_embeds for k in emb}
-            c = stepper.make_conditioning(emb, bs, pooled, add_time_ids)
+            ckey = (id(prompt_pair), bs, height, width)
+            c = None if prompt_pair.dynamic_crops else cond_cache.get(ckey)
+            if c is None:
+                c = cond_cache[ckey] = stepper.make_conditioning(emb, bs, pooled, add_time_ids)
             lr_now = lr_scheduler.get_last_lr()[0]
             loss = stepper.train_step(denoised_latents, current_timestep, c, prompt_pair.action,
                                       prompt_pair.guidance_scale, lr=lr_now)
@@ -140,7 +154,8 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
             torch.nn.utils.clip_grad_norm_(network.parameters(), max_norm=0.2)
             optimizer.step()
         lr_scheduler.step()
-        lv = float(loss.item())
+        lv = float(loss.item())  # the one host sync per step, as the reference's loss.item() (train_lora_xl.py:346)
+        network.training_losses.append(lv)
         pbar.set_description(f"Loss*1k: {lv * 1000:.4f}")
         if save_file and rank_ == 0 and i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1:
             save_path.mkdir(parents=True, exist_ok=True)

@@ -208,6 +208,7 @@ class _UNetFn(torch.autograd.Function):
             down, up = flat[:n_down], flat[n_down:]
         eps = engine.forward(sample, timestep, ehs, text_embeds, time_ids, down, up, multiplier, save)
         ctx.engine = engine if save else None
+        ctx.gen = engine.tape_generation() if save else 0
         ctx.n_down = n_down
         ctx.keep = (sample, ehs, text_embeds, time_ids, flat)  # borrowed by the engine until backward
         return eps
@@ -217,6 +218,12 @@ class _UNetFn(torch.autograd.Function):
         if ctx.engine is None:
             return (None,) * 10
         flat = ctx.keep[4]
+        # the engine holds ONE tape: a later saved forward, a change of shape (replan) or an earlier backward drops it
+        if ctx.engine.tape_generation() != ctx.gen:
+            raise _native.SmiError(
+                "backward through a UNet output whose saved activations are gone: the engine keeps the tape of the LAST "
+                "grad-enabled forward only (a later grad-enabled forward, a call at another resolution / batch, or a "
+                "previous backward released it). Call backward before the next grad-enabled UNet call.")
         g = torch.zeros_like(flat)
         ctx.engine.backward(d_eps.contiguous().float(), g[:ctx.n_down], g[ctx.n_down:])
         return None, None, None, None, None, None, None, g, None, None
@@ -282,19 +289,23 @@ class UNet2DConditionModel(nn.Module):
         n_adapted = n if n_adapted is None else n_adapted
         net = self._lora_network
         sites = net.engine_sites() if net is not None else []
-        key = (self.dtype, str(self.device), h, w, ctx_len, tuple((s["target"], s["off_down"], s["off_up"], s["rank"],
-                                                                   s["scale"]) for s in sites))
-        if (self._engine is not None and self._engine_key == key and n <= self._engine.batch
-                and n_adapted <= self._engine.batch_adapted):
-            return self._engine
+        # packed weights depend on dtype / device / adapted sites only; shapes are plans of the same engine
+        key = (self.dtype, str(self.device), tuple((s["target"], s["off_down"], s["off_up"], s["rank"], s["scale"])
+                                                   for s in sites))
+        if self._engine is not None and self._engine_key == key:
+            e = self._engine
+            if (h, w, ctx_len) == (e.h, e.w, e.ctx_len) and n <= e.batch and n_adapted <= e.batch_adapted:
+                return e
+            if (h, w, ctx_len) == (e.h, e.w, e.ctx_len):  # same latents, larger batch: grow, never shrink
+                n, n_adapted = max(n, e.batch), max(n_adapted, e.batch_adapted)
+            e.plan(n, min(n, n_adapted), h, w, ctx_len)
+            return e
         if self.device.type != "cuda":
             raise _native.SmiError("the UNet runs only on an MI355X through the HIP engine; move it to a cuda "
                                    "device with unet.to(device, dtype) (there is no CPU fallback)")
         if self.dtype not in _native.DTYPE_CODE:
             raise _native.SmiError(f"engine dtypes are float16/bfloat16, got {self.dtype}")
-        if self._engine is not None:
-            n = max(n, self._engine.batch)
-            n_adapted = max(n_adapted, self._engine.batch_adapted)
+        if self._engine is not None:  # other dtype / device / adaptor set: the packed weights change
             self._engine.close()
             self._engine = None
         state = {k: v.detach() for k, v in self.state_dict().items()}

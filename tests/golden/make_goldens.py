@@ -27,6 +27,8 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 
 warnings.filterwarnings("ignore")
+# Adam eps of the "smooth" trajectories (section 7): >> the largest |gradient| of the run (recorded in the manifest)
+SMOOTH_EPS = {"tiny_sd1x": 1e-3, "tiny_sdxl": 1e-3}
 
 
 def install_diffusers_stub():
@@ -158,6 +160,105 @@ def main():
             pooled = {k: torch.randn(1, pdim, generator=g) for k in keys}
         return emb, pooled
 
+    def run_trajectory(model, cfg, sched, xl, tag, opt_kwargs, full_sd):
+        """Six steps of the reference loop (train_lora.py:155-300 / train_lora_xl.py:165-351) driven through the
+        reference's own helper functions on the oracle UNet."""
+        torch.manual_seed(1234)
+        unet = U.init_synthetic_(U.UNet2DConditionModel(cfg), seed=0)
+        unet.requires_grad_(False)
+        unet.eval()
+        torch.manual_seed(1)  # LoRA down init uses the global RNG (lora.py:123)
+        net = ref_lora.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, target_replace=["Attention"],
+                                   train_method="noxattn")
+        for l in (net.unet_loras[0], net.unet_loras[-1]):
+            tensors[f"{tag}/init/{l.lora_name}.lora_down.weight"] = l.lora_down.weight.detach().clone()
+        keys = ["target", "positive", "neutral", "unconditional"] + (["negative"] if xl else [])
+        emb, pooled = synth_embeds(cfg, keys, seed=4)
+        okw = opt_kwargs or {}
+        if not xl:
+            opt = ref_tu.get_optimizer("AdamW")(net.prepare_optimizer_params(), lr=2e-3, **okw)
+            lrs = ref_tu.get_lr_scheduler("constant", opt, max_iterations=8, lr_min=2e-5)
+        else:  # hard-coded in train_lora_xl.py:104-105 (only eps differs in the `smooth` variant of section 7)
+            opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6, **okw)
+            lrs = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50, eta_min=1e-6)
+        s = _S()
+        s.action = "enhance"
+        s.guidance_scale = 4.0
+        s.batch_size = 1
+        pair = ref_pu.PromptEmbedsPair(torch.nn.MSELoss(), None, None, None, None, None, s)
+        max_steps = 8
+        losses, gmax = [], []
+        # NOTE: no reseed here -- the loop continues the global RNG stream left by the LoRA init (seed 1 above),
+        # exactly as a real run of the reference script does; the product's train() is checked against this.
+        for it in range(6):
+            with torch.no_grad():
+                sched.set_timesteps(max_steps)
+                opt.zero_grad()
+                _pair_idx = torch.randint(0, 1, (1,)).item()
+                timesteps_to = torch.randint(1, max_steps, (1,)).item()
+                latents = ref_tu.get_initial_latents(sched, 1, 128, 128, 1)
+                tid = ref_tu.get_add_time_ids(128, 128, dynamic_crops=False, dtype=torch.float32) if xl else None
+
+                def cat(key):
+                    te = ref_tu.concat_embeddings(emb["unconditional"], emb[key], 1)
+                    if not xl:
+                        return dict(text_embeddings=te)
+                    return dict(text_embeddings=te,
+                                add_text_embeddings=ref_tu.concat_embeddings(pooled["unconditional"], pooled[key], 1),
+                                add_time_ids=ref_tu.concat_embeddings(tid, tid, 1))
+
+                with net:
+                    if not xl:
+                        denoised = ref_tu.diffusion(unet, sched, latents, cat("target")["text_embeddings"],
+                                                    start_timesteps=0, total_timesteps=timesteps_to, guidance_scale=3)
+                    else:
+                        denoised = ref_tu.diffusion_xl(unet, sched, latents, **cat("target"), start_timesteps=0,
+                                                       total_timesteps=timesteps_to, guidance_scale=1.0)
+                sched.set_timesteps(1000)
+                cur_t = sched.timesteps[int(timesteps_to * 1000 / max_steps)]
+                pn = ref_tu.predict_noise_xl if xl else ref_tu.predict_noise
+                positive = pn(unet, sched, cur_t, denoised, **cat("positive"), guidance_scale=1)
+                neutral = pn(unet, sched, cur_t, denoised, **cat("neutral"), guidance_scale=1)
+                negative = pn(unet, sched, cur_t, denoised, **cat("negative" if xl else "unconditional"),
+                              guidance_scale=1)
+            with net:
+                target = pn(unet, sched, cur_t, denoised, **cat("target"), guidance_scale=1)
+            loss = pair.loss(target_latents=target, positive_latents=positive, neutral_latents=neutral,
+                             negative_latents=negative)
+            losses.append(loss.item())
+            loss.backward()
+            gmax.append(max(float(p.grad.abs().max()) for p in net.parameters()))
+            if xl:
+                torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=0.2)
+            opt.step()
+            lrs.step()
+            if it == 0:
+                for k, v in net.state_dict().items():
+                    if "alpha" not in k:
+                        pass
+                tensors[f"{tag}/step0_timestep"] = torch.tensor([float(cur_t)])
+                tensors[f"{tag}/step0_denoised"] = denoised.contiguous()
+                tensors[f"{tag}/step0_target"] = target.detach().contiguous()
+        sd = net.state_dict()
+        # keep the fixture small: store three full modules + per-tensor norms of all
+        keep = [k for k in sd if any(s_ in k for s_ in ("down_blocks_1_attentions_0_transformer_blocks_0_attn1_to_q",
+                                                        "mid_block_attentions_0_transformer_blocks_0_attn1_to_out_0",
+                                                        "up_blocks_1_attentions_2_transformer_blocks_0_attn1_to_v"))]
+        if full_sd:
+            keep = [k for k in sd if "alpha" not in k]
+        for k in keep:
+            tensors[f"{tag}/sd/{k}"] = sd[k].detach().clone().contiguous()
+        manifest[tag] = {
+            "losses": losses, "iterations": 6, "max_denoising_steps": max_steps,
+            "norms": {k: float(v.float().norm()) for k, v in sd.items()},
+            "seeds": {"lora_init_then_loop": 1, "unet": 0, "emb": 4},
+            "optimizer": "AdamW lr 2e-3 constant" if not xl else "AdamW lr 1e-4 wd 1e-6 cosine(50,1e-6) clip 0.2",
+        }
+        if opt_kwargs:
+            manifest[tag]["optimizer_kwargs"] = dict(opt_kwargs)
+            manifest[tag]["grad_absmax_per_step"] = gmax
+
+
     for model, cfg, sched_name in [("tiny_sd1x", U.tiny_sd1x_config(), "ddim"),
                                    ("tiny_sdxl", U.tiny_sdxl_config(), "euler_a")]:
         xl = cfg.addition_embed_type == "text_time"
@@ -202,93 +303,7 @@ def main():
                                         "latent_seed": 3, "unet_seed": 0, "scheduler": sched_name}
 
         # -------------------------------------------------------------- (5) training trajectory, reference step order
-        torch.manual_seed(1234)
-        unet = U.init_synthetic_(U.UNet2DConditionModel(cfg), seed=0)
-        unet.requires_grad_(False)
-        unet.eval()
-        torch.manual_seed(1)  # LoRA down init uses the global RNG (lora.py:123)
-        net = ref_lora.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, target_replace=["Attention"],
-                                   train_method="noxattn")
-        for l in (net.unet_loras[0], net.unet_loras[-1]):
-            tensors[f"traj/{model}/init/{l.lora_name}.lora_down.weight"] = l.lora_down.weight.detach().clone()
-        keys = ["target", "positive", "neutral", "unconditional"] + (["negative"] if xl else [])
-        emb, pooled = synth_embeds(cfg, keys, seed=4)
-        if not xl:
-            opt = ref_tu.get_optimizer("AdamW")(net.prepare_optimizer_params(), lr=2e-3)
-            lrs = ref_tu.get_lr_scheduler("constant", opt, max_iterations=8, lr_min=2e-5)
-        else:
-            opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6)  # hard-coded, train_lora_xl.py:104
-            lrs = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50, eta_min=1e-6)
-        s = _S()
-        s.action = "enhance"
-        s.guidance_scale = 4.0
-        s.batch_size = 1
-        pair = ref_pu.PromptEmbedsPair(torch.nn.MSELoss(), None, None, None, None, None, s)
-        max_steps = 8
-        losses = []
-        # NOTE: no reseed here -- the loop continues the global RNG stream left by the LoRA init (seed 1 above),
-        # exactly as a real run of the reference script does; the product's train() is checked against this.
-        for it in range(6):
-            with torch.no_grad():
-                sched.set_timesteps(max_steps)
-                opt.zero_grad()
-                _pair_idx = torch.randint(0, 1, (1,)).item()
-                timesteps_to = torch.randint(1, max_steps, (1,)).item()
-                latents = ref_tu.get_initial_latents(sched, 1, 128, 128, 1)
-                tid = ref_tu.get_add_time_ids(128, 128, dynamic_crops=False, dtype=torch.float32) if xl else None
-
-                def cat(key):
-                    te = ref_tu.concat_embeddings(emb["unconditional"], emb[key], 1)
-                    if not xl:
-                        return dict(text_embeddings=te)
-                    return dict(text_embeddings=te,
-                                add_text_embeddings=ref_tu.concat_embeddings(pooled["unconditional"], pooled[key], 1),
-                                add_time_ids=ref_tu.concat_embeddings(tid, tid, 1))
-
-                with net:
-                    if not xl:
-                        denoised = ref_tu.diffusion(unet, sched, latents, cat("target")["text_embeddings"],
-                                                    start_timesteps=0, total_timesteps=timesteps_to, guidance_scale=3)
-                    else:
-                        denoised = ref_tu.diffusion_xl(unet, sched, latents, **cat("target"), start_timesteps=0,
-                                                       total_timesteps=timesteps_to, guidance_scale=1.0)
-                sched.set_timesteps(1000)
-                cur_t = sched.timesteps[int(timesteps_to * 1000 / max_steps)]
-                pn = ref_tu.predict_noise_xl if xl else ref_tu.predict_noise
-                positive = pn(unet, sched, cur_t, denoised, **cat("positive"), guidance_scale=1)
-                neutral = pn(unet, sched, cur_t, denoised, **cat("neutral"), guidance_scale=1)
-                negative = pn(unet, sched, cur_t, denoised, **cat("negative" if xl else "unconditional"),
-                              guidance_scale=1)
-            with net:
-                target = pn(unet, sched, cur_t, denoised, **cat("target"), guidance_scale=1)
-            loss = pair.loss(target_latents=target, positive_latents=positive, neutral_latents=neutral,
-                             negative_latents=negative)
-            losses.append(loss.item())
-            loss.backward()
-            if xl:
-                torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=0.2)
-            opt.step()
-            lrs.step()
-            if it == 0:
-                for k, v in net.state_dict().items():
-                    if "alpha" not in k:
-                        pass
-                tensors[f"traj/{model}/step0_timestep"] = torch.tensor([float(cur_t)])
-                tensors[f"traj/{model}/step0_denoised"] = denoised.contiguous()
-                tensors[f"traj/{model}/step0_target"] = target.detach().contiguous()
-        sd = net.state_dict()
-        # keep the fixture small: store three full modules + per-tensor norms of all
-        keep = [k for k in sd if any(s_ in k for s_ in ("down_blocks_1_attentions_0_transformer_blocks_0_attn1_to_q",
-                                                        "mid_block_attentions_0_transformer_blocks_0_attn1_to_out_0",
-                                                        "up_blocks_1_attentions_2_transformer_blocks_0_attn1_to_v"))]
-        for k in keep:
-            tensors[f"traj/{model}/sd/{k}"] = sd[k].detach().clone().contiguous()
-        manifest[f"traj/{model}"] = {
-            "losses": losses, "iterations": 6, "max_denoising_steps": max_steps,
-            "norms": {k: float(v.float().norm()) for k, v in sd.items()},
-            "seeds": {"lora_init_then_loop": 1, "unet": 0, "emb": 4},
-            "optimizer": "AdamW lr 2e-3 constant" if not xl else "AdamW lr 1e-4 wd 1e-6 cosine(50,1e-6) clip 0.2",
-        }
+        run_trajectory(model, cfg, sched, xl, f"traj/{model}", None, full_sd=False)
 
     # ------------------------------------------------------------------ (6) helpers: add_time_ids, LR traces, config
     tensors["add_time_ids"] = ref_tu.get_add_time_ids(1024, 768, dynamic_crops=False, dtype=torch.float32)
@@ -331,6 +346,16 @@ def main():
     manifest["prompt_defaults"] = json.loads(ref_pu.PromptSettings(target="x").json())
     torch.manual_seed(5)
     manifest["random_resolution_bucket_seed5"] = [list(ref_tu.get_random_resolution_in_bucket(512)) for _ in range(8)]
+
+    # ------------------------------------------------------------------ (7) "smooth" trajectories: the same loop with
+    # Adam's eps raised far above the gradient scale, so the update is ~ lr * g / eps (proportional to the gradient)
+    # instead of ~ lr * sign(g): 16-bit gradient noise is then NOT amplified and the final LoRA tensors of an fp16
+    # engine run can be compared element-wise.  Full state dicts are stored.  (Placed last: fixtures (1)-(6) unchanged.)
+    for model, cfg, sched_name in [("tiny_sd1x", U.tiny_sd1x_config(), "ddim"),
+                                   ("tiny_sdxl", U.tiny_sdxl_config(), "euler_a")]:
+        xl = cfg.addition_embed_type == "text_time"
+        sched = S.create_noise_scheduler_ref(sched_name)
+        run_trajectory(model, cfg, sched, xl, f"traj_smooth/{model}", {"eps": SMOOTH_EPS[model]}, full_sd=True)
 
     save_file(tensors, os.path.join(OUT, "harness_goldens.safetensors"))
     with open(os.path.join(OUT, "harness_goldens.json"), "w") as f:

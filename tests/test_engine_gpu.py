@@ -241,3 +241,65 @@ def test_rank8_and_ragged_nonsquare_latents(model):
             den += b.norm().item() ** 2
     glob = (num / den) ** 0.5
     assert glob < 8e-3, f"rank-8 / ragged global LoRA-grad rel err {glob:.3e}"
+
+
+def test_alternating_resolutions_replan_without_repacking():
+    """Engine lifetime (reference: dynamic_resolution draws a new bucket EVERY step, T/train_util.py:1085-1097): switching
+    latent sizes must only re-plan the activation arenas -- no weight-packing kernel may run again (smi_engine_stats)
+    -- and must give bit-identical results to a fresh engine at that size."""
+    ocfg, ou, onet, pu, pnet = build_pair("tiny_sdxl", torch.float16)
+    sizes = [(16, 16), (24, 16), (16, 16), (8, 24), (24, 16)]
+    got = []
+    with torch.no_grad(), pnet:
+        for i, (h, w) in enumerate(sizes):
+            g = torch.Generator().manual_seed(30 + h * 100 + w)
+            x = torch.randn(2, 4, h, w, generator=g).cuda()
+            ctx = torch.randn(2, 77, ocfg.cross_attention_dim, generator=g).cuda()
+            pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
+            add = {"text_embeds": torch.randn(2, pdim, generator=g).cuda(),
+                   "time_ids": torch.tensor([[h * 8.0, w * 8.0, 0, 0, h * 8.0, w * 8.0]] * 2).cuda()}
+            got.append(pu(x, 499.0, encoder_hidden_states=ctx, added_cond_kwargs=add).sample.clone())
+            st = pu._engine.stats()
+            if i == 0:
+                packs = st["pack_launches"]
+                assert packs > 0
+            assert st["pack_launches"] == packs, f"weights re-packed on a shape change ({h}x{w})"
+            assert st["replans"] == i, st
+        eng = pu._engine
+    assert torch.equal(got[0], got[2]) and torch.equal(got[1], got[4])
+    # fresh engine at the second size: same bits
+    ocfg2, _, _, pu2, pnet2 = build_pair("tiny_sdxl", torch.float16)
+    h, w = sizes[1]
+    g = torch.Generator().manual_seed(30 + h * 100 + w)
+    x = torch.randn(2, 4, h, w, generator=g).cuda()
+    ctx = torch.randn(2, 77, ocfg.cross_attention_dim, generator=g).cuda()
+    pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
+    add = {"text_embeds": torch.randn(2, pdim, generator=g).cuda(),
+           "time_ids": torch.tensor([[h * 8.0, w * 8.0, 0, 0, h * 8.0, w * 8.0]] * 2).cuda()}
+    with torch.no_grad(), pnet2:
+        fresh = pu2(x, 499.0, encoder_hidden_states=ctx, added_cond_kwargs=add).sample
+    assert pu2._engine.stats()["replans"] == 0
+    assert torch.equal(fresh, got[1])
+    assert eng is pu._engine
+
+
+def test_backward_through_a_superseded_forward_fails_loudly():
+    """The engine keeps ONE tape.  A second grad-enabled forward (or a change of shape) drops the first one's saved
+    activations: backward through the older output must raise, not silently replay the newer tape."""
+    from sliders_conceptmod_amd._native import SmiError
+    ocfg, ou, onet, pu, pnet = build_pair("tiny_sd1x", torch.float16)
+    x, ctx, add = inputs(ocfg, 2, 16)
+    with pnet:
+        a = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda()).sample
+        b = pu(x.cuda(), 301.0, encoder_hidden_states=ctx.cuda()).sample
+    with pytest.raises(SmiError, match="saved activations are gone"):
+        a.sum().backward()
+    b.sum().backward()  # the live tape still works
+    assert pnet.flat.grad is not None and float(pnet.flat.grad.abs().max()) > 0
+    with pnet:
+        c = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda()).sample
+    with torch.no_grad():
+        x2 = torch.randn(2, 4, 24, 24).cuda()
+        pu(x2, 499.0, encoder_hidden_states=ctx.cuda())  # another shape: replan drops the tape
+    with pytest.raises(SmiError, match="saved activations are gone"):
+        c.sum().backward()

@@ -13,13 +13,19 @@ from oracle import slider_ref as R
 from oracle import unet_ref as OU
 
 
+# fp16 bars: 1.5 x the measured values; north_star asks for 1e-3 relative
+EPS_BAR = 1.7e-3
+GRAD_BAR = 3.5e-3
+
+
 def rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("model", ["sd1x", "sdxl"])
-def test_real_architecture_forward_and_lora_gradients(model):
+@pytest.mark.parametrize("model,lora_rank", [("sd1x", 4), ("sdxl", 4), ("sdxl", 8)])
+def test_real_architecture_forward_and_lora_gradients(model, lora_rank):
+    """("sdxl", 8) is BASELINE config 4's per-GPU shard (SD-XL, rank 8) at the real widths."""
     import sliders_conceptmod_amd.lora as L
     import sliders_conceptmod_amd.unet as PU
     torch.set_num_threads(16)
@@ -29,10 +35,11 @@ def test_real_architecture_forward_and_lora_gradients(model):
     pu.load_state_dict(ou.state_dict())
     pu = pu.to("cuda", torch.float16).requires_grad_(False).eval()
     torch.manual_seed(1)
-    onet = R.LoRANetworkRef(ou, 4, 1.0, 1.0, "noxattn")
+    onet = R.LoRANetworkRef(ou, lora_rank, 1.0, 1.0, "noxattn")
     torch.manual_seed(1)
-    pnet = L.LoRANetwork(pu, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    pnet = L.LoRANetwork(pu, rank=lora_rank, multiplier=1.0, alpha=1.0, train_method="noxattn")
     assert len(pnet.unet_loras) == {"sd1x": 64, "sdxl": 280}[model]
+    assert pnet.flat.numel() == {"sd1x": 399360, "sdxl": 2662400}[model] * lora_rank // 4
     g = torch.Generator().manual_seed(2)
     with torch.no_grad():
         for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
@@ -70,10 +77,12 @@ def test_real_architecture_forward_and_lora_gradients(model):
             num += float((a.cpu() - b).norm() ** 2)
             den += float(b.norm() ** 2)
     eg = (num / den) ** 0.5
-    print(f"{model}: eps rel err frozen {e0:.2e}, adapted {e1:.2e}; global LoRA-grad rel err {eg:.2e}")
-    assert e0 < 3e-3 and e1 < 3e-3, (e0, e1)
+    print(f"{model} r{lora_rank}: eps rel err frozen {e0:.2e}, adapted {e1:.2e}; global LoRA-grad rel err {eg:.2e}")
+    assert e0 < EPS_BAR and e1 < EPS_BAR, (e0, e1)
     assert rel(got, got0) > 1e-4  # the adaptor does something
-    assert eg < 1.5e-2, eg
+    assert eg < GRAD_BAR, eg
+    if lora_rank != 4:
+        return
 
     # ---- the same network in bf16 (BASELINE configs[1] trains SD-1.5 in bf16) against the same fp32 oracle results:
     # 8 mantissa bits -> the storage-noise floor is ~8x the fp16 one (test_engine_gpu.py: 6.5e-3 .. 9e-3 on the tiny nets)
@@ -99,6 +108,65 @@ def test_real_architecture_forward_and_lora_gradients(model):
     print(f"{model} bf16: eps rel err adapted {eb:.2e}; global LoRA-grad rel err {egb:.2e}")
     assert eb < 1.5e-2, eb      # measured 9.0e-3 (SD-1.x), 6.0e-3 (SD-XL)
     assert egb < 4e-2, egb      # measured 1.3e-2, 1.8e-2
+
+
+def test_image_slider_step_real_sdxl_widths_vs_oracle():
+    """BASELINE config 5's per-GPU work (SD-XL image slider, scales +/-1) at the real widths, 32x32 latents: the
+    two-sided step (slider +s on the `high` latent, -s on the `low` one, two backward()s accumulating) against the
+    oracle's autograd on the same inputs."""
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.model_util as MU
+    import sliders_conceptmod_amd.unet as PU
+    from sliders_conceptmod_amd.prompt_util import PromptEmbedsXL
+    from sliders_conceptmod_amd.train_lora_scale_xl import image_slider_step
+    from oracle import sched_ref as S
+    torch.set_num_threads(16)
+    ocfg = OU.sdxl_config()
+    ou = OU.init_synthetic_(OU.UNet2DConditionModel(ocfg), seed=0).requires_grad_(False).eval()
+    pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(ocfg)))
+    pu.load_state_dict(ou.state_dict())
+    pu = pu.to("cuda", torch.float16).requires_grad_(False).eval()
+    torch.manual_seed(1)
+    onet = R.LoRANetworkRef(ou, 4, 1.0, 1.0, "noxattn")
+    torch.manual_seed(1)
+    pnet = L.LoRANetwork(pu, rank=4, alpha=1.0, train_method="noxattn")
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+            w = torch.randn(lo.lora_up.weight.shape, generator=g) * 0.02
+            lo.lora_up.weight.copy_(w)
+            lp.lora_up.weight.copy_(w)
+    pnet.to("cuda")
+    g = torch.Generator().manual_seed(5)
+    emb = {k: (torch.randn(1, 77, 2048, generator=g), torch.randn(1, 1280, generator=g)) for k in ("pos", "neu")}
+    lat = {k: torch.randn(1, 4, 32, 32, generator=g) for k in ("low", "high")}
+    noise = torch.randn(1, 4, 32, 32, generator=g)
+    tid = torch.tensor([[256.0, 256, 0, 0, 256, 256]])
+    osch, psch = S.create_noise_scheduler_ref("ddim"), MU.create_noise_scheduler("ddim")
+    osch.set_timesteps(1000), psch.set_timesteps(1000)
+    t = psch.timesteps[600]
+    scale = 1.0  # --scales '1,-1'
+    for sgn, key, ek in ((+1.0, "high", "pos"), (-1.0, "low", "neu")):
+        onet.set_lora_slider(sgn * scale)
+        x = osch.add_noise(lat[key], noise, torch.tensor([int(t)]))
+        te, pe = emb[ek]
+        with onet:
+            pred = R.predict_noise_xl(ou, osch, osch.timesteps[600], x, torch.cat([te, te]), torch.cat([pe, pe]),
+                                      torch.cat([tid, tid]), guidance_scale=1.0)
+        torch.nn.functional.mse_loss(pred, noise).backward()
+    nl = psch.add_noise(lat["low"], noise, t).cuda()
+    nh = psch.add_noise(lat["high"], noise, t).cuda()
+    pos = PromptEmbedsXL(emb["pos"][0].cuda().half(), emb["pos"][1].cuda().half())
+    neu = PromptEmbedsXL(emb["neu"][0].cuda().half(), emb["neu"][1].cuda().half())
+    image_slider_step(pu, pnet, psch, nl, nh, noise.cuda(), noise.cuda(), t, pos, neu, tid.cuda(), scale)
+    num = den = 0.0
+    for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+        for a, b in ((lp.lora_down.grad, lo.lora_down.weight.grad), (lp.lora_up.grad, lo.lora_up.weight.grad)):
+            num += float((a.cpu() - b).norm() ** 2)
+            den += float(b.norm() ** 2)
+    eg = (num / den) ** 0.5
+    print(f"sdxl image slider (+/-{scale:g}): accumulated LoRA-grad rel err {eg:.2e}")
+    assert eg < GRAD_BAR, eg
 
 
 def test_kernel_generations_agree_at_headline_size(tmp_path):

@@ -26,7 +26,7 @@ class GoldenEncoder:
             self.pooled = {k: torch.randn(1, pdim, generator=g) for k in keys}
 
 
-def make(model, tmp_path, xl):
+def make(model, tmp_path, xl, optimizer_args=""):
     import sliders_conceptmod_amd.config_util as CU
     import sliders_conceptmod_amd.model_util as MU
     import sliders_conceptmod_amd.prompt_util as PRU
@@ -49,7 +49,8 @@ def make(model, tmp_path, xl):
         prompts_file="unused", pretrained_model=CU.PretrainedModelConfig(name_or_path="injected"),
         network=CU.NetworkConfig(type="lierla", rank=4, alpha=1.0, training_method="noxattn"),
         train=CU.TrainConfig(precision="float16", noise_scheduler="euler_a" if xl else "ddim", iterations=6, lr=2e-3,
-                             optimizer="AdamW", lr_scheduler="constant", max_denoising_steps=8, cfg=1.0),
+                             optimizer="AdamW", optimizer_args=optimizer_args, lr_scheduler="constant",
+                             max_denoising_steps=8, cfg=1.0),
         save=CU.SaveConfig(name="t", path=str(tmp_path), per_steps=1000), logging=CU.LoggingConfig(),
         other=CU.OtherConfig())
     kw = dict(target="target", positive="positive", neutral="neutral", unconditional="unconditional", action="enhance",
@@ -78,10 +79,11 @@ def test_cli_train_reproduces_reference_trajectory(goldens, tmp_path, model):
                     on_step_complete=lambda i, l: losses.append(l))
     out = tmp_path / ("t_last.safetensors" if xl else "t_last.pt")
     assert out.exists()
-    if not xl:
-        assert len(losses) == 6
-        for a, b in zip(losses, meta["losses"]):
-            assert abs(a - b) <= 0.03 * abs(b), (losses, meta["losses"])
+    if xl:
+        losses = net.training_losses
+    assert len(losses) == 6
+    for a, b in zip(losses, meta["losses"]):  # measured: within 0.6 % (fp16 engine vs the fp32 reference run)
+        assert abs(a - b) <= 0.015 * abs(b), (losses, meta["losses"])
     sd = net.state_dict()
     assert set(sd.keys()) == set(meta["norms"].keys())
     # weights after 6 AdamW steps: Adam's sign-like first steps amplify 16-bit gradient noise on tiny gradients, so
@@ -94,6 +96,62 @@ def test_cli_train_reproduces_reference_trajectory(goldens, tmp_path, model):
         a, b = sd[k.split("/sd/")[1]].float().cpu().flatten(), t[k].float().flatten()
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.97, f"{k}: cosine {cos:.4f}"
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("model", ["tiny_sd1x", "tiny_sdxl"])
+def test_cli_train_final_lora_tensors_elementwise(goldens, tmp_path, model, fused):
+    """The saved LoRA tensors themselves, element by element, against the reference harness' "smooth" trajectory
+    (tests/golden/make_goldens.py section 7: the same six steps with Adam eps = 1e-3 >> |gradient|, so the update is
+    proportional to the gradient instead of its sign and 16-bit gradient noise is not amplified).  SD-1.x goes through
+    the config's `optimizer_args`, SD-XL through train(optimizer_kwargs=...) (its AdamW is hard-coded, as in the
+    reference); `fused` runs the same steps through SliderStep (native loss / clip / AdamW kernels)."""
+    t, man = goldens
+    meta = man[f"traj_smooth/{model}"]
+    xl = model.endswith("xl")
+    if fused and not xl:
+        pytest.skip("--fused_step is an SD-XL trainer option")
+    eps = meta["optimizer_kwargs"]["eps"]
+    cfg, prompts, models = make(model, tmp_path, xl, optimizer_args="" if xl else f"eps={eps}")
+    losses = []
+    torch.manual_seed(1)
+    if xl:
+        from sliders_conceptmod_amd.train_lora_xl import train
+        net = train(cfg, prompts, torch.device("cuda:0"), rank=4, save_file=True, models=models, fused_step=fused,
+                    optimizer_kwargs={"eps": eps})
+        losses = net.training_losses
+    else:
+        from sliders_conceptmod_amd.train_lora import train
+        net = train(cfg, prompts, torch.device("cuda:0"), models=models,
+                    on_step_complete=lambda i, l: losses.append(l))
+    for a, b in zip(losses, meta["losses"]):
+        assert abs(a - b) <= 0.015 * abs(b), (losses, meta["losses"])
+    # reload what was written (the saved file is the product) and compare every stored tensor
+    out = tmp_path / ("t_last.safetensors" if xl else "t_last.pt")
+    if xl:
+        from safetensors.torch import load_file
+        saved = load_file(str(out))
+    else:
+        saved = torch.load(out, weights_only=True)
+    keys = [k for k in t if k.startswith(f"traj_smooth/{model}/sd/")]
+    assert len(keys) == 2 * len(net.unet_loras)
+    worst = 0.0
+    num = den = 0.0
+    for k in keys:
+        name = k.split("/sd/")[1]
+        ref = t[k].float()
+        live = net.state_dict()[name].float().cpu()
+        # fp32 master weights vs the fp32 reference run: element-wise, relative to the tensor's largest element
+        err = float((live - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        num += float((live - ref).norm() ** 2)
+        den += float(ref.norm() ** 2)
+        # the file holds them in the train dtype (fp16), as the reference writes them: one storage rounding on top
+        tol16 = 2.0 ** -10 * float(ref.abs().max()) + 6e-8  # half an fp16 ulp at the top + the subnormal step
+        assert float((saved[name].float() - live).abs().max()) <= tol16, name
+    print(f"{model} fused={fused}: worst element error / tensor max = {worst:.2e}, global rel = {(num / den) ** 0.5:.2e}")
+    assert (num / den) ** 0.5 <= 2e-3
+    assert worst <= 1e-2, worst
 
 
 def test_fused_step_matches_autograd_step(goldens, tmp_path):
