@@ -200,6 +200,8 @@ int smi_op_lora_down(int dtype, const void* x, const float* a, float* xa, int m,
 /* out[m, r] (fp32) = x[m, k] * s[r, k]^T on 16-bit operands, r = 16 or 32, k % 128 == 0: the engine's kernel for
  * xa = x * lora_down^T and dxa = dy * lora_up (T/lora.py:134-138 and its backward) on the 16-bit shadow parameters */
 int smi_op_lora_skinny(int dtype, const void* x, const void* s, float* out, int m, int r, int k, void* stream);
+/* dw[r, k] += alpha * p[m, r]^T x[m, k]: the engine's grouped weight-gradient reduction (T/lora.py:134-138 backward)
+ * run on a one-job table.  scratch: ceil(m / 64) * r * k + 256 floats (partials + the table). */
 int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m, int k, int r, float alpha,
                       float* scratch, void* stream);
 

@@ -1,6 +1,7 @@
 // HBM-bound elementwise / data-movement kernels (16-byte lanes, grid-stride) and the slider-step ops
 // (CFG combine, guidance loss + gradient, global-norm clip + AdamW, scheduler update).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace smi {
 namespace {
@@ -80,11 +81,11 @@ __global__ void copy_cols_kernel(const T* __restrict__ src, int64_t lds, T* __re
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const void* __restrict__ src, int src_f32, T* __restrict__ dst, int Nb, int C,
                                     int HW, int Cpad, float scale, const float* __restrict__ scale_dev) {
-  const float sc = scale_dev ? scale * scale_dev[0] : scale;
   GSTRIDE(i, (int64_t)Nb * HW * Cpad) {
     const int c = (int)(i % Cpad);
     const int64_t pix = i / Cpad;
     const int64_t n = pix / HW, hw = pix - n * HW;
+    const float sc = scale_dev ? scale * scale_dev[n] : scale;  // scale_dev: one factor per sample
     float v = 0.f;
     if (c < C) {
       const int64_t si = (n * C + c) * HW + hw;
@@ -159,19 +160,26 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __rest
   if (threadIdx.x == 0)
     partial[blockIdx.x] = OP == 0 ? fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-// scale = 2^floor(log2(16 / amax)) (power of two: exact), out[0] = scale, out[1] = 1/scale
-__global__ void grad_scale_finalize_kernel(const float* __restrict__ partial, int np, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float amax = 0.f;
-    for (int i = 0; i < np; ++i) amax = fmaxf(amax, partial[i]);
+// one block per sample: scale[j] = 2^floor(log2(target / max|x_j|)) (power of two: exact), inv[j] = 1 / scale[j]
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ x, int64_t per, float* __restrict__ out,
+                                                         int inv_off, float target) {
+  __shared__ float sh[4];
+  const float* xs = x + (int64_t)blockIdx.x * per;
+  float amax = 0.f;
+  for (int64_t i = threadIdx.x; i < per; i += 256) amax = fmaxf(amax, fabsf(xs[i]));
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     float s = 1.f;
     if (amax > 0.f && isfinite(amax)) {
-      int e = (int)floorf(log2f(16.f / amax));
+      int e = (int)floorf(log2f(target / amax));
       e = e > 40 ? 40 : (e < -40 ? -40 : e);
       s = exp2f((float)e);
     }
-    out[0] = s;
-    out[1] = 1.f / s;
+    out[blockIdx.x] = s;
+    out[inv_off + blockIdx.x] = 1.f / s;
   }
 }
 
@@ -342,11 +350,15 @@ int launch_pool2x2_sum(int dtype, const void* du, void* dx, int Nb, int H, int W
   SMI_HIP(hipGetLastError());
   return 0;
 }
-// scale_out: [0]=scale, [1]=1/scale, [2..2+256) scratch
-int launch_grad_scale(const float* d_eps, int64_t n, float* scale_out, hipStream_t stream) {
-  const int np = ew_grid(n) > 256 ? 256 : ew_grid(n);
-  hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(np), dim3(256), 0, stream, d_eps, n, scale_out + 2);
-  hipLaunchKernelGGL(grad_scale_finalize_kernel, dim3(1), dim3(64), 0, stream, scale_out + 2, np, scale_out);
+// scale_out[j] = scale of sample j, scale_out[inv_off + j] = its inverse
+int launch_grad_scale(const float* d_eps, int n_samples, int64_t per_sample, float* scale_out, int inv_off,
+                      hipStream_t stream) {
+  static const float target = [] {
+    const char* v = getenv("SMI_GRAD_TARGET_LOG2");
+    return exp2f(v ? (float)atoi(v) : 4.f);
+  }();
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(n_samples), dim3(256), 0, stream, d_eps, per_sample, scale_out, inv_off,
+                     target);
   SMI_HIP(hipGetLastError());
   return 0;
 }

@@ -182,37 +182,20 @@ struct smi_engine {
   smi_unet_config cfg{};
   int dtype = 0;
   hipStream_t stream = nullptr;
-  // Second stream for the LoRA weight-gradient reductions of the backward.  They are many small, latency-bound
-  // launches (rank-4 outer products over 4-16 k rows) that nothing in the dX chain waits for: each site forks them
-  // off behind an event and the main stream carries on with the dX GEMM; backward() joins before it returns.  Safe
-  // because both arenas are bump-allocated (no buffer is recycled inside one backward).  SMI_SIDE_STREAM=0 disables.
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool side_used = false;
-  // gradient buffers the side stream still reads.  A dy can live on as another tensor's gradient (accumulate()
-  // aliases it) and then be added to IN PLACE by the main stream: such a write first joins the side stream.
-  std::vector<const void*> side_reads;
-  hipStream_t wgrad_stream(const void* dy) {
-    if (dry || prof_on || !side) return stream;  // class timing uses events on the main stream only
-    (void)hipEventRecord(ev_fork, stream);
-    (void)hipStreamWaitEvent(side, ev_fork, 0);
-    side_used = true;
-    side_reads.push_back(dy);
-    return side;
-  }
-  void join_side() {
-    if (!side_used) return;
-    (void)hipEventRecord(ev_join, side);
-    (void)hipStreamWaitEvent(stream, ev_join, 0);
-    side_used = false;
-    side_reads.clear();
-  }
-  void before_inplace_write(const void* g) {
-    for (const void* q : side_reads)
-      if (q == g) {
-        join_side();
-        return;
-      }
+  // LoRA weight gradients are DEFERRED: every adapted Linear appends its rank-r reductions to `wjobs` while the
+  // backward runs and one grouped launch at the end does them all (lora.hip).  The arenas never recycle memory inside a
+  // backward, so x, xa and dxa are still there; the one operand at risk is dY, which can live on as another tensor's
+  // gradient (accumulate() aliases it) and would then be added to IN PLACE: such buffers are `pinned`, and a write
+  // that would land on a pinned buffer goes to a fresh one instead (grad_slot / accumulate).
+  std::vector<WgradJob> wjobs;
+  std::vector<WgradJob> wjobs_uploaded;  // what the device table holds (same addresses every step of a plan: no re-upload)
+  WgradJob* wjobs_dev = nullptr;
+  size_t wjobs_cap = 0;
+  std::vector<const void*> pinned;
+  bool is_pinned(const void* g) const {
+    for (const void* q : pinned)
+      if (q == g) return true;
+    return false;
   }
   bool dry = false;
   bool err = false;
@@ -226,7 +209,9 @@ struct smi_engine {
   Arena wpack;     // packed weights + persistent small buffers
   Arena arena[2];  // 0: no-grad passes, 1: differentiated pass + backward
   Arena* cur = nullptr;
-  float* gscale = nullptr;  // [0]=scale [1]=1/scale [2..258) scratch
+  // per-sample power-of-two loss scales: [0, MAXS) scale of adapted sample j, [MAXS, 2 MAXS) its inverse, then scratch
+  static constexpr int MAXS = 1024;
+  float* gscale = nullptr;
 
   std::unordered_map<std::string, const smi_weight*> wmap;
   std::unordered_map<std::string, const smi_lora_site*> smap;
@@ -306,7 +291,24 @@ struct smi_engine {
   struct ProfEv {
     int cat;
     hipEvent_t a, b;
+    std::string tag;
+    double flops;
   };
+  // SMI_PROF_DUMP=1: per-shape table of the GEMM / conv launches of the profiled step on stderr (smi_profile_read)
+  struct TagAcc {
+    double ms = 0, flops = 0;
+    int n = 0;
+  };
+  std::unordered_map<std::string, TagAcc> prof_tags;
+  bool prof_dump = getenv("SMI_PROF_DUMP") != nullptr;
+  std::string gemm_tag(const GemmParams& p) const {
+    char b[160];
+    snprintf(b, sizeof(b), "%s M=%d N=%d K=%d%s%s%s%s%s%s", p.conv ? "conv" : "gemm", p.M, p.N, p.K, p.bias ? " bias" : "",
+             p.res ? " res" : "", p.lora_r ? " lora" : "", p.geglu_out ? " geglu" : "", p.rowvec ? " rowvec" : "",
+             p.out_f32 ? " f32" : "");
+    return b;
+  }
+  std::string next_tag;
   std::vector<ProfEv> prof_ev;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[SMI_PROF_NCAT] = {0};
@@ -329,6 +331,7 @@ struct smi_engine {
     pe.cat = cat;
     pe.a = prof_event();
     pe.b = prof_event();
+    pe.flops = flops;
     (void)hipEventRecord(pe.a, stream);
     prof_ev.push_back(pe);
     prof_flops[cat] += flops;
@@ -337,6 +340,8 @@ struct smi_engine {
   }
   void prof_end() {
     if (!prof_on) return;
+    prof_ev.back().tag.swap(next_tag);  // set while the call's arguments were evaluated
+    next_tag.clear();
     (void)hipEventRecord(prof_ev.back().b, stream);
   }
   void prof_collect() {  // host-synchronising
@@ -345,6 +350,12 @@ struct smi_engine {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, pe.a, pe.b);
       prof_ms[pe.cat] += ms;
+      if (prof_dump && !pe.tag.empty()) {
+        TagAcc& t = prof_tags[pe.tag];
+        t.ms += ms;
+        t.flops += pe.flops;
+        t.n += 1;
+      }
       prof_pool.push_back(pe.a);
       prof_pool.push_back(pe.b);
     }
@@ -376,19 +387,31 @@ struct smi_engine {
   float* alloc_f32(size_t count) { return (float*)arena_alloc(count * sizeof(float)); }
   void* alloc_t(int64_t rows, int cols) { return arena_alloc((size_t)rows * cols * esz()); }
 
-  // gradient slot of t: returns buffer to write; `had` tells whether a gradient is already accumulated there
-  void* grad_slot(Ten* t, bool& had) {
-    had = t->g != nullptr;
-    if (!had) t->g = alloc_t(MA(t), t->cols);
-    else before_inplace_write(t->g);
-    return t->g;
+  // gradient slot of t: `out` is where the producer writes, `add` (may be null, may equal out) what is already
+  // accumulated there and has to be added in the same pass.  Out of place when the old buffer is pinned.
+  struct Slot {
+    void* add;
+    void* out;
+  };
+  Slot grad_slot(Ten* t) {
+    Slot s;
+    if (!t->g) {
+      s.add = nullptr;
+      s.out = t->g = alloc_t(MA(t), t->cols);
+    } else if (is_pinned(t->g)) {
+      s.add = t->g;
+      s.out = t->g = alloc_t(MA(t), t->cols);
+    } else {
+      s.add = s.out = t->g;
+    }
+    return s;
   }
   void accumulate(Ten* t, void* g) {
     if (!t->g) {
-      t->g = g;  // alias: g is dead after its producer's closure
+      t->g = g;  // alias: g is dead after its producer's closure (unless pinned: then nobody writes to it)
     } else {
-      before_inplace_write(t->g);
-      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, t->g, g, t->g, MA(t) * t->cols, stream));
+      Slot s = grad_slot(t);
+      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, s.add, g, s.out, MA(t) * t->cols, stream));
     }
   }
 
@@ -685,7 +708,9 @@ struct smi_engine {
     }
     build_kv_group();
     finish_lora();
-    gscale = (float*)pack_alloc(260 * sizeof(float));
+    gscale = (float*)pack_alloc((2 * MAXS + 256) * sizeof(float));
+    wjobs_cap = 2 * (sites.size() + 8);
+    wjobs_dev = (WgradJob*)pack_alloc(wjobs_cap * sizeof(WgradJob));
     for (size_t i = 0; i < sites.size(); ++i)
       if (!site_used[i] && !err) {
         set_error("LoRA target '%s' is not an attention projection this engine adapts (lierla/attention-only)",
@@ -753,7 +778,7 @@ struct smi_engine {
         RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0,
              launch_lora_skinny(dtype, g.A, g.lda, g.W, xa, g.ldc, g.M, g.N, g.K, stream));
       else
-        RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0, launch_gemm(g, stream));
+        RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(g), 0) : 0, launch_gemm(g, stream)));
     }
     GemmParams p;
     p.dtype = dtype;
@@ -782,7 +807,7 @@ struct smi_engine {
       p.lora_row0 = (int)x->arow0;
     }
     RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
-         launch_gemm(p, stream));
+         (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     y->arow0 = x->arow0;
     y->ng = lon || x->ng || (res && res->ng);
     if (saving && y->ng) {
@@ -803,7 +828,6 @@ struct smi_engine {
       const int r = L->rank;
       const int rp = L->rows_pad;
       dxa = alloc_f32((size_t)M * rp);
-      float* scratch = alloc_f32(std::max(lora_wgrad_scratch_floats(M, cs, r), lora_wgrad_scratch_floats(M, L->in, rtot)));
       {  // dxa[M, rows_pad] = dy * upT^T : one MFMA GEMM against the block-diagonal 16-bit shadow of lora_up
         GemmParams g;
         g.dtype = dtype;
@@ -820,26 +844,42 @@ struct smi_engine {
           RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0,
                launch_lora_skinny(dtype, g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K, stream));
         else
-          RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0, launch_gemm(g, stream));
+          RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(g), 0) : 0, launch_gemm(g, stream)));
       }
-      hipStream_t ws = wgrad_stream(dy);  // forks behind the dxa GEMM above
-      for (int s = 0; s < L->nseg; ++s) {
-        const char* dys = (const char*)dy + (size_t)s * cs * esz();
-        // d(up_s)[n][q] += lscale/S * sum_m dy[m][s*cs+n] * xa[m][s*r+q]
-        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, xa + s * r, rp, dys, L->out, d_up + L->off_up + (int64_t)s * cs * r, 1, r, M,
-                              cs, r, lscale, gscale + 1, scratch, ws));
-      }
-      // d(down)[q'][k] += lscale/S * sum_m dxa[m][q'] * x[m][k] for all fused segments at once: the down matrices of
-      // a fused projection are one contiguous [r_tot, in] block, so x is read once (r_tot <= 32)
+      // deferred (see `wjobs`): d(up)[n][q] += lscale/S * sum_m dy[m][n] * xa[m][seg(n)*r + q]  for all segments,
+      //                         d(down)[q'][k] += lscale/S * sum_m dxa[m][q'] * x[m][k]       (q' over the r_tot rows)
+      const int rps = (int)(M / std::max(n_ad, 1));
+      auto push = [&](const void* X, int64_t ldx, const float* P, float* dW, int64_t so_r, int64_t so_k, int K, int rr,
+                      int seg_cols) {
+        WgradJob j{};
+        j.X = X;
+        j.ldx = ldx;
+        j.P = P;
+        j.ldp = rp;
+        j.dW = dW;
+        j.so_r = so_r;
+        j.so_k = so_k;
+        j.M = M;
+        j.K = K;
+        j.r = rr;
+        j.seg_cols = seg_cols;
+        j.rows_per_sample = rps;
+        j.row_scale = gscale + MAXS;
+        j.alpha = lscale;
+        wgrad_job_plan(j);
+        j.partial = alloc_f32(wgrad_job_scratch_floats(j));
+        wjobs.push_back(j);
+      };
+      push(dy, L->out, xa, d_up ? d_up + L->off_up : nullptr, 1, r, L->out, r, L->nseg > 1 ? cs : 0);
       if (rtot <= 32) {
-        RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa, L->rows_pad, PA(x), x->cols, d_down + L->off_down, L->in, 1, M,
-                              L->in, rtot, lscale, gscale + 1, scratch, ws));
+        push(PA(x), x->cols, dxa, d_down ? d_down + L->off_down : nullptr, L->in, 1, L->in, rtot, 0);
       } else {
-        for (int s = 0; s < L->nseg; ++s)
-          RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_wgrad(dtype, dxa + s * r, L->rows_pad, PA(x), x->cols,
-                                d_down + L->off_down + (int64_t)s * r * L->in, L->in, 1, M, L->in, r, lscale, gscale + 1,
-                                scratch, ws));
+        for (int sg = 0; sg < L->nseg; ++sg) {
+          push(PA(x), x->cols, dxa + sg * r, d_down ? d_down + L->off_down + (int64_t)sg * r * L->in : nullptr, L->in, 1,
+               L->in, r, 0);
+        }
       }
+      pinned.push_back(dy);
     }
     if (x->ng) {
       if (!L->Wt && !dry) {
@@ -847,20 +887,19 @@ struct smi_engine {
         err = true;
         return;
       }
-      bool had;
-      void* dx = grad_slot(x, had);
+      const Slot gs = grad_slot(x);
       GemmParams p;
       p.dtype = dtype;
       p.A = dy;
       p.lda = L->out;
       p.W = L->Wt;
-      p.C = dx;
+      p.C = gs.out;
       p.ldc = L->in;
       p.M = M;
       p.N = L->in;
       p.K = L->out;
-      if (had) {
-        p.res = dx;
+      if (gs.add) {
+        p.res = gs.add;
         p.ldr = L->in;
       }
       if (lon) {
@@ -874,7 +913,7 @@ struct smi_engine {
         p.lora_scale = lscale;
       }
       RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
-           launch_gemm(p, stream));
+           (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     }
   }
 
@@ -887,9 +926,8 @@ struct smi_engine {
       const Norm* np = &nm;
       tape.push_back([=]() {
         if (!y->g) return;
-        bool had;
-        void* dx = grad_slot(x, had);
-        RUNP(SMI_PROF_NORM, 0.0, 6.0 * MA(x) * x->cols, launch_layernorm_bwd(dtype, PA(x), y->g, np->gamma, st + x->arow0 * 2, had ? dx : nullptr, dx, (int)MA(x), x->cols,
+        const Slot gs = grad_slot(x);
+        RUNP(SMI_PROF_NORM, 0.0, 6.0 * MA(x) * x->cols, launch_layernorm_bwd(dtype, PA(x), y->g, np->gamma, st + x->arow0 * 2, gs.add, gs.out, (int)MA(x), x->cols,
                                  stream));
       });
     }
@@ -910,11 +948,10 @@ struct smi_engine {
       const Norm* np = &nm;
       tape.push_back([=]() {
         if (!y->g) return;
-        bool had;
-        void* dx = grad_slot(x, had);
+        const Slot gs = grad_slot(x);
         float* scr = alloc_f32(npart + (size_t)2 * x->n * C);
         const int n0 = (int)(x->arow0 / HW);  // first adapted sample
-        RUNP(SMI_PROF_NORM, 0.0, 6.0 * MA(x) * x->cols, launch_groupnorm_bwd(dtype, PA(x), y->g, np->gamma, np->beta, ab + (size_t)n0 * C, ab + (size_t)(x->n + n0) * C, mr + (size_t)n0 * G * 2, had ? dx : nullptr, dx, scr, x->n - n0, HW,
+        RUNP(SMI_PROF_NORM, 0.0, 6.0 * MA(x) * x->cols, launch_groupnorm_bwd(dtype, PA(x), y->g, np->gamma, np->beta, ab + (size_t)n0 * C, ab + (size_t)(x->n + n0) * C, mr + (size_t)n0 * G * 2, gs.add, gs.out, scr, x->n - n0, HW,
                                  C, G, silu ? 1 : 0, stream));
       });
     }
@@ -951,7 +988,7 @@ struct smi_engine {
     p.C = pj->p;
     p.geglu_row0 = need_proj ? (int)x->arow0 : p.M;
     RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + 0.5 * (double)p.M * p.N),
-         launch_gemm(p, stream));
+         (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     out->ng = x->ng;
     pj->ng = x->ng;
     if (saving && out->ng) {
@@ -962,8 +999,7 @@ struct smi_engine {
       });
       tape.push_back([=]() {
         if (!out->g) return;
-        bool had;
-        void* dp = grad_slot(pj, had);
+        void* dp = grad_slot(pj).out;  // the projection has a single consumer: nothing accumulated yet
         RUNP(SMI_PROF_ELEM, 0.0, 10.0 * MA(pj) * C4, launch_geglu_bwd(dtype, PA(pj), out->g, dp, (int)MA(pj), C4, stream));
       });
     }
@@ -978,14 +1014,13 @@ struct smi_engine {
     if (saving && y->ng) {
       tape.push_back([=]() {
         if (!y->g) return;
-        bool had;
-        void* dp = grad_slot(pj, had);
-        if (had) {  // never happens in this graph (proj has a single consumer); kept for safety
+        const Slot gs = grad_slot(pj);
+        if (gs.add) {  // never happens in this graph (proj has a single consumer); kept for safety
           void* tmp = alloc_t(MA(pj), pj->cols);
           RUNP(SMI_PROF_ELEM, 0.0, 10.0 * MA(pj) * C4, launch_geglu_bwd(dtype, PA(pj), y->g, tmp, (int)MA(pj), C4, stream));
-          RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dp, tmp, dp, MA(pj) * pj->cols, stream));
+          RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, gs.add, tmp, gs.out, MA(pj) * pj->cols, stream));
         } else {
-          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * MA(pj) * C4, launch_geglu_bwd(dtype, PA(pj), y->g, dp, (int)MA(pj), C4, stream));
+          RUNP(SMI_PROF_ELEM, 0.0, 10.0 * MA(pj) * C4, launch_geglu_bwd(dtype, PA(pj), y->g, gs.out, (int)MA(pj), C4, stream));
         }
       });
     }
@@ -1037,20 +1072,20 @@ struct smi_engine {
         b.dO = o->g;
         b.lddo = C;
         b.delta = alloc_f32((size_t)b.B * heads * Nq);
-        bool had;
+        // q|k|v, q and kv tensors have a single consumer (this attention): their slots are fresh
         if (qkv) {
-          char* g = (char*)grad_slot(qkv, had);
+          char* g = (char*)grad_slot(qkv).out;
           b.dQ = g;
           b.dK = g + (size_t)C * esz();
           b.dV = g + (size_t)2 * C * esz();
           b.lddq = b.lddk = b.lddv = 3 * C;
         } else {
           if (q->ng) {
-            b.dQ = grad_slot(q, had);
+            b.dQ = grad_slot(q).out;
             b.lddq = C;
           }
           if (kv && kv->ng) {
-            char* g = (char*)grad_slot(kv, had);
+            char* g = (char*)grad_slot(kv).out;
             b.dK = g;
             b.dV = g + (size_t)C * esz();
             b.lddk = b.lddv = 2 * C;
@@ -1096,7 +1131,7 @@ struct smi_engine {
       p.ldr = res->cols;
     }
     RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 2.0 * ((double)x->rows * c.Cin + (double)p.N * p.K + (double)p.M * p.N),
-         launch_gemm(p, stream));
+         (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     y->ng = x->ng || (res && res->ng);
     if (saving && y->ng) {
       const Conv* cp = &c;
@@ -1105,8 +1140,7 @@ struct smi_engine {
         if (!dy) return;
         if (res && res->ng) accumulate(res, dy);
         if (!x->ng) return;
-        bool had;
-        void* dx = grad_slot(x, had);
+        const Slot gs = grad_slot(x);
         GemmParams b;
         b.dtype = dtype;
         b.conv = 1;
@@ -1121,12 +1155,12 @@ struct smi_engine {
           b.Hin = b.Hout = Hin;
           b.Win = b.Wout = Win;
           b.M = (int)MA(x);
-          b.C = dx;
-          if (had) {
-            b.res = dx;
+          b.C = gs.out;
+          if (gs.add) {
+            b.res = gs.add;
             b.ldr = cp->Cin;
           }
-          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
+          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(b), 0) : 0, launch_gemm(b, stream)));
         } else if (cp->mode == 1) {  // gradient of the stride-2 conv: gather dY at (i + 1 - k) / 2
           b.Hin = Hout;
           b.Win = Wout;
@@ -1135,25 +1169,25 @@ struct smi_engine {
           b.stride = 2;
           b.transposed = 1;
           b.M = (int)MA(x);
-          b.C = dx;
-          if (had) {
-            b.res = dx;
+          b.C = gs.out;
+          if (gs.add) {
+            b.res = gs.add;
             b.ldr = cp->Cin;
           }
-          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
+          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(b), 0) : 0, launch_gemm(b, stream)));
         } else {  // upsample + conv: gradient on the 2x grid, then 2x2 sum-pool
           void* du = alloc_t(MA(y), cp->Cin);
           b.Hin = b.Hout = Hout;
           b.Win = b.Wout = Wout;
           b.M = (int)MA(y);
           b.C = du;
-          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, launch_gemm(b, stream));
-          if (had) {
+          RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(b), 0) : 0, launch_gemm(b, stream)));
+          if (gs.add) {
             void* tmp = alloc_t(MA(x), cp->Cin);
             RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, tmp, b.Nb, Hin, Win, cp->Cin, stream));
-            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dx, tmp, dx, MA(x) * x->cols, stream));
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, gs.add, tmp, gs.out, MA(x) * x->cols, stream));
           } else {
-            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, dx, b.Nb, Hin, Win, cp->Cin, stream));
+            RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, gs.out, b.Nb, Hin, Win, cp->Cin, stream));
           }
         }
       });
@@ -1174,15 +1208,14 @@ struct smi_engine {
         for (int i = 0; i < 2; ++i) {
           Ten* t = parts[i];
           if (t->ng) {
-            bool had;
-            void* dst = grad_slot(t, had);
-            if (had) {
+            const Slot gs = grad_slot(t);
+            if (gs.add) {
               void* tmp = alloc_t(MA(t), t->cols);
               RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, tmp, t->cols, 0, (int)MA(t),
                                    t->cols, stream));
-              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, dst, tmp, dst, MA(t) * t->cols, stream));
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, gs.add, tmp, gs.out, MA(t) * t->cols, stream));
             } else {
-              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, dst, t->cols, 0, (int)MA(t),
+              RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, (char*)y->g + (size_t)col0 * esz(), y->cols, gs.out, t->cols, 0, (int)MA(t),
                                    t->cols, stream));
             }
           }
@@ -1309,7 +1342,7 @@ struct smi_engine {
       p.Hin = p.Hout = H;
       p.Win = p.Wout = Wd_;
       p.Cin = 64;
-      RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * 9 * cfg.in_channels, 0.0, launch_gemm(p, stream));
+      RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * 9 * cfg.in_channels, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     }
 
     std::vector<Ten*> skips;
@@ -1361,15 +1394,14 @@ struct smi_engine {
       p.Hin = p.Hout = H;
       p.Win = p.Wout = Wd_;
       p.Cin = C0;
-      RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 0.0, launch_gemm(p, stream));
+      RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     }
     RUN(launch_nhwc_to_nchw_f32((const float*)y->p, eps_out, n, cfg.out_channels, HW, stream));
     y->ng = hn->ng;
     if (saving && y->ng) {
       tape.push_back([=]() {
         if (!y->g) return;
-        bool had;
-        void* dx = grad_slot(hn, had);
+        void* dx = grad_slot(hn).out;
         GemmParams b;
         b.dtype = dtype;
         b.conv = 1;
@@ -1384,7 +1416,7 @@ struct smi_engine {
         b.Hin = b.Hout = H;
         b.Win = b.Wout = Wd_;
         b.Cin = 64;
-        RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * 9 * cfg.out_channels, 0.0, launch_gemm(b, stream));
+        RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * 9 * cfg.out_channels, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(b), 0) : 0, launch_gemm(b, stream)));
       });
     }
     if (save) {
@@ -1420,12 +1452,44 @@ struct smi_engine {
       tape_valid = false;
       return 0;
     }
-    const int64_t cnt = (int64_t)n * cfg.out_channels * HW;
-    RUN(launch_grad_scale(d_eps, cnt, gscale, stream));
+    if (n > MAXS && !dry) {
+      set_error("smi_unet_backward: %d adapted samples exceed the %d per-sample loss scales", n, MAXS);
+      return -1;
+    }
+    wjobs.clear();
+    pinned.clear();
+    // one power-of-two loss scale PER SAMPLE (from max|d_eps[sample]|): a sample's backward arithmetic then does not
+    // depend on which other samples share the batch -- W ranks on shards == one rank on the global batch
+    RUN(launch_grad_scale(d_eps, n, (int64_t)cfg.out_channels * HW, gscale, MAXS, stream));
     y->g = alloc_t(MA(y), 64);
     RUN(launch_nchw_to_nhwc_scaled(dtype, d_eps, y->g, n, cfg.out_channels, HW, 64, gscale, stream));
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();
-    join_side();
+    if (!wjobs.empty() && !err) {  // every LoRA weight gradient of this pass: one grouped launch per accumulator class
+      wgrad_grouped_finish(wjobs);
+      if (!dry) {
+        if (wjobs.size() > wjobs_cap) {
+          set_error("internal: %zu weight-gradient jobs exceed the table (%zu)", wjobs.size(), wjobs_cap);
+          return -1;
+        }
+        const bool same = wjobs_uploaded.size() == wjobs.size() &&
+                          memcmp(wjobs_uploaded.data(), wjobs.data(), wjobs.size() * sizeof(WgradJob)) == 0;
+        if (!same) {  // bump allocation gives the same addresses every step of a plan: uploaded once, then reused
+          wjobs_uploaded = wjobs;
+          if (hipMemcpyAsync(wjobs_dev, wjobs_uploaded.data(), wjobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice,
+                             stream) != hipSuccess) {
+            set_error("hipMemcpyAsync (weight-gradient job table) failed");
+            return -1;
+          }
+        }
+        double bytes = 0.0, flops = 0.0;
+        for (const auto& j : wjobs) {
+          bytes += (double)j.M * j.K * 2.0;
+          flops += 2.0 * j.M * j.K * j.r;
+        }
+        RUNP(SMI_PROF_LORA, flops, bytes, launch_lora_wgrad_grouped(dtype, wjobs, wjobs_dev, stream));
+      }
+    }
+    pinned.clear();
     tape.clear();
     tape_valid = false;
     if (cur->overflow && !dry) {
@@ -1544,29 +1608,12 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
   }
   // the weight table is only borrowed during creation
   e->wmap.clear();
-  {
-    const char* ss = getenv("SMI_SIDE_STREAM");
-    if (!ss || strcmp(ss, "0") != 0) {
-      if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        e->side = nullptr;  // no second stream: everything stays on the caller's stream
-      }
-    }
-  }
   *out = e;
   return 0;
 }
 
 void smi_destroy(smi_engine* e) {
   if (!e) return;
-  if (e->side) {
-    (void)hipStreamSynchronize(e->side);
-    (void)hipStreamDestroy(e->side);
-  }
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   delete e;
 }
 
@@ -1600,7 +1647,7 @@ int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ct
   const size_t have = arena ? (size_t)((char*)arena + arena_bytes - base) : e->arena_home_bytes;
   SMI_CHECK(r[1] + r[2] <= have, "arena too small for batch %d (%d adapted), %dx%d latents: need %zu bytes, got %zu", batch,
             batch_adapted, h, w, r[1] + r[2] + 2 * 4096, arena ? arena_bytes : e->arena_home_bytes);
-  e->join_side();
+  e->wjobs_uploaded.clear();
   e->max_n = batch;
   e->max_n_ad = batch_adapted;
   e->lat_h = h;
@@ -1674,6 +1721,17 @@ int smi_profile_enable(smi_engine* e, int enable) {
 int smi_profile_read(smi_engine* e, double* ms, double* flops, double* bytes, int64_t* launches) {
   SMI_CHECK(e && ms && flops && bytes && launches, "NULL argument");
   e->prof_collect();
+  if (e->prof_dump && !e->prof_tags.empty()) {
+    std::vector<std::pair<std::string, smi_engine::TagAcc>> v(e->prof_tags.begin(), e->prof_tags.end());
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.ms > b.second.ms; });
+    double tot = 0;
+    for (auto& kv : v) tot += kv.second.ms;
+    fprintf(stderr, "[smi profile] GEMM / conv launches by shape (%.2f ms total)\n", tot);
+    for (auto& kv : v)
+      fprintf(stderr, "  %8.3f ms %5d x %8.1f us %7.0f TF/s  %s\n", kv.second.ms, kv.second.n,
+              kv.second.ms * 1e3 / kv.second.n, kv.second.flops / (kv.second.ms * 1e-3) / 1e12, kv.first.c_str());
+    e->prof_tags.clear();
+  }
   for (int i = 0; i < SMI_PROF_NCAT; ++i) {
     ms[i] = e->prof_ms[i];
     flops[i] = e->prof_flops[i];
@@ -1843,7 +1901,28 @@ int smi_op_lora_skinny(int dtype, const void* x, const void* s, float* out, int 
 }
 int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m, int k, int r, float alpha,
                       float* scratch, void* stream) {
-  return launch_lora_wgrad(dtype, p, r, x, k, dw, k, 1, m, k, r, alpha, nullptr, scratch, (hipStream_t)stream);
+  // the engine's grouped reduction with a one-job table (scratch: the job's partials followed by the table itself)
+  std::vector<WgradJob> jobs(1);
+  WgradJob& j = jobs[0];
+  j = WgradJob{};
+  j.X = x;
+  j.ldx = k;
+  j.P = p;
+  j.ldp = r;
+  j.dW = dw;
+  j.so_r = k;
+  j.so_k = 1;
+  j.M = m;
+  j.K = k;
+  j.r = r;
+  j.rows_per_sample = m;
+  j.alpha = alpha;
+  wgrad_job_plan(j);
+  j.partial = scratch;
+  wgrad_grouped_finish(jobs);
+  WgradJob* dev = reinterpret_cast<WgradJob*>(scratch + ((wgrad_job_scratch_floats(j) + 63) / 64) * 64);
+  SMI_HIP(hipMemcpyAsync(dev, jobs.data(), sizeof(WgradJob), hipMemcpyHostToDevice, (hipStream_t)stream));
+  return launch_lora_wgrad_grouped(dtype, jobs, dev, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 // return 0 on success or a negative code after smi::set_error().  Activations are token-major ("NHWC"):
 // an image tensor is [N, H*W, C] with C contiguous.
 #pragma once
+#include <vector>
+
 #include "smi_common.h"
 
 namespace smi {
@@ -114,7 +116,7 @@ int launch_copy_cols(int dtype, const void* src, int64_t lds, void* dst, int64_t
                      hipStream_t stream);
 int launch_nchw_to_nhwc(int dtype, const void* src, int src_f32, void* dst, int Nb, int C, int HW, int Cpad,
                         float scale, hipStream_t stream);
-// f32 NCHW -> T token-major, multiplied by the device scalar *scale_dev (backward entry: loss-scaled d_eps)
+// f32 NCHW -> T token-major, sample n multiplied by scale_dev[n] (backward entry: loss-scaled d_eps)
 int launch_nchw_to_nhwc_scaled(int dtype, const float* src, void* dst, int Nb, int C, int HW, int Cpad,
                                const float* scale_dev, hipStream_t stream);
 int launch_nhwc_to_nchw_f32(const float* src, float* dst, int Nb, int C, int HW, hipStream_t stream);
@@ -122,9 +124,11 @@ int launch_nhwc_to_nchw_f32(const float* src, float* dst, int Nb, int C, int HW,
 int launch_timestep_embed(int dtype, const float* vals, void* out, int n, int dim, hipStream_t stream);
 // dx[n,h,w,c] = sum_{2x2} du[n,2h+a,2w+b,c]
 int launch_pool2x2_sum(int dtype, const void* du, void* dx, int Nb, int H, int W, int C, hipStream_t stream);
-// power-of-two loss scale chosen on device from amax|d_eps| (keeps 16-bit activation gradients in range):
-// scale_out[0] = scale, [1] = 1/scale, [2..258) scratch
-int launch_grad_scale(const float* d_eps, int64_t n, float* scale_out, hipStream_t stream);
+// power-of-two loss scales chosen on device, ONE PER SAMPLE, from max|d_eps[sample]| (keeps 16-bit activation
+// gradients in range and makes a sample's backward independent of its batch mates):
+// scale_out[j] = scale, scale_out[inv_off + j] = 1 / scale
+int launch_grad_scale(const float* d_eps, int n_samples, int64_t per_sample, float* scale_out, int inv_off,
+                      hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // LoRA skinny kernels (rank r <= 32)
@@ -132,12 +136,22 @@ int launch_grad_scale(const float* d_eps, int64_t n, float* scale_out, hipStream
 // xa[M, r] = X[M, K] (T, row stride ldx) * A[r, K]^T (f32)                       (lora_down / dXA = dY * up)
 int launch_lora_down(int dtype, const void* X, int64_t ldx, const float* A, int64_t lda_r, int64_t lda_k, float* xa,
                      int64_t ld_xa, int M, int K, int r, hipStream_t stream);
-// dW[r, K] (+)= alpha * P[M, r]^T (f32) * X[M, K] (T)     -- weight-gradient reduction over M
-//   out index (q, k) -> dW[q*so_r + k*so_k]
-int launch_lora_wgrad(int dtype, const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r,
-                      int64_t so_k, int M, int K, int r, float alpha, const float* alpha_dev, float* scratch,
-                      hipStream_t stream);
-size_t lora_wgrad_scratch_floats(int M, int K, int r);
+// dW (+)= alpha * P[M, r]^T (f32) * X[M, K] (T) -- weight-gradient reductions over M.
+// Grouped form (lora.hip): one table entry per rank-r reduction dW (+)= alpha * P^T X of a backward pass
+struct WgradJob {
+  const void* X;           // [M, K] 16-bit operand (dY or the layer input), row stride ldx
+  const float* P;          // [M, >= nseg * r] fp32 (xa or dxa), row stride ldp
+  float* dW;               // output base; element (q, k) at dW[q * so_r + k * so_k]
+  float* partial;          // scratch [nsplit][r][K]
+  const float* row_scale;  // per-sample factors applied to the rows of P (nullptr: none)
+  int64_t ldx, ldp, so_r, so_k;
+  int M, K, r, seg_cols, rows_per_sample;
+  float alpha;
+  int cw, ncolblk, rows_per_wg, nsplit;  // geometry (wgrad_job_plan)
+  int wg0, fb0;                          // first workgroup in the partial / final grid (wgrad_grouped_finish)
+};
+void wgrad_job_plan(WgradJob& j);
+size_t wgrad_job_scratch_floats(const WgradJob& j);
 // 16-bit shadow copies of the LoRA matrices as GEMM operands (see lora.hip); sites_dev: device array of HostLoraPrepSite
 struct HostLoraPrepSite {
   int64_t off_down, off_up, dst_down, dst_up;
@@ -147,6 +161,9 @@ struct HostLoraPrepSite {
 bool lora_skinny_supported(const void* X, int64_t ldx, const void* S, const float* out, int ldo, int M, int R, int K);
 int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, float* out, int ldo, int M, int R, int K,
                        hipStream_t stream);
+int wgrad_grouped_finish(std::vector<WgradJob>& jobs);
+int launch_lora_wgrad_grouped(int dtype, const std::vector<WgradJob>& jobs, const WgradJob* jobs_dev,
+                              hipStream_t stream);
 int launch_lora_prep(int dtype, const void* sites_dev, int n_sites, const float* down, const float* up, void* shadow,
                      hipStream_t stream);
 

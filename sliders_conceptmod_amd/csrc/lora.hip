@@ -3,11 +3,13 @@
 //  lora_down : xa[M, r] = X[M, K] * A[r, K]^T          one wave per row, K split over the lanes in 16-byte
 //              vectors, r accumulators per lane, butterfly (wavefront shuffle) reduction.  Also used for
 //              dXA = dY * up (A given with strides).  HBM-bound: reads X once.
-//  lora_wgrad: dW[r, K] += alpha * P[M, r]^T * X[M, K]   weight-gradient reduction over the 4*N tokens:
-//              each thread owns one 16-byte column vector of X and r x 8 f32 accumulators, workgroups split M;
-//              per-workgroup partials are combined through LDS and a second fixed-order pass (deterministic).
+//  lora_wgrad: dW[r, K] += alpha * P[M, r]^T * X[M, K]   weight-gradient reduction over the 4*N tokens, GROUPED: all
+//              reductions of a backward pass in one launch from a job table (see "Grouped weight-gradient reduction").
 // The up-projection delta itself (xa * up^T) is fused into the GEMM epilogue (gemm.hip).
 #include "kernels.h"
+
+#include <algorithm>
+#include <vector>
 
 namespace smi {
 namespace {
@@ -46,102 +48,6 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const T* __restrict__ X,
   }
 }
 
-// rows of M per workgroup in the weight-gradient reduction: small enough that even M = 4096 fills the chip
-__host__ __device__ inline int wg_rows(int M) { return M >= 8192 ? 32 : 16; }
-
-template <typename T, int R>
-__global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(const float* __restrict__ P, int64_t ldp,
-                                                                 const T* __restrict__ X, int64_t ldx,
-                                                                 float* __restrict__ partial, int M, int K, int r) {
-  extern __shared__ float red[];  // [rpar * ncb][8]
-  const int cols8 = K / 8;
-  const int colblk = blockIdx.y;  // blocks of up to 256 column vectors
-  const int ncb = min(256, cols8 - colblk * 256);
-  const int rpar = 256 / ncb >= 1 ? 256 / ncb : 1;
-  const int tid = threadIdx.x;
-  const int rsub = tid / ncb;
-  const int cl = tid - rsub * ncb;
-  const bool active = rsub < rpar;
-  const int col = colblk * 256 + cl;
-  const int rows = wg_rows(M);
-  const int row0 = blockIdx.x * rows;
-  const int row1 = min(M, row0 + rows);
-  float acc[R][8];
-#pragma unroll
-  for (int q = 0; q < R; ++q)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
-  if (active) {
-    // 4 independent row loads in flight per thread (the loop is otherwise a chain of dependent HBM latencies)
-    for (int m0 = row0 + rsub; m0 < row1; m0 += 4 * rpar) {
-      Pack8<T> xv[4];
-      float pv[4][R];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int m = m0 + u * rpar;
-        const bool ok = m < row1;
-        xv[u].u = ok ? *reinterpret_cast<const u32x4*>(X + (int64_t)m * ldx + col * 8) : u32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < R; ++q) pv[u][q] = (ok && q < r) ? P[(int64_t)m * ldp + q] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < R; ++q)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[q][e] += pv[u][q] * to_f(xv[u].e[e]);
-    }
-  }
-  // combine the rpar row-slices through LDS in a fixed order
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    if (q < r) {  // r is block-uniform: the barriers below are reached by every thread or by none
-      __syncthreads();
-      if (active) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(rsub * ncb + cl) * 8 + e] = acc[q][e];
-      }
-      __syncthreads();
-      if (tid < ncb) {
-        float* out = partial + ((int64_t)blockIdx.x * r + q) * K + (colblk * 256 + tid) * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float s = 0.f;
-          for (int rs = 0; rs < rpar; ++rs) s += red[(rs * ncb + tid) * 8 + e];
-          out[e] = s;
-        }
-      }
-    }
-  }
-}
-
-// dW[q*so_r + k*so_k] += alpha * alpha_dev * sum_s partial[s][q][k]   (fixed summation order: deterministic)
-// block = 32 consecutive outputs x 8 split-groups; group g sums splits g, g+8, ...; LDS combines the 8 groups.
-__global__ __launch_bounds__(256) void lora_wgrad_final_kernel(const float* __restrict__ partial, int nsplit,
-                                                               float* __restrict__ dW, int64_t so_r, int64_t so_k,
-                                                               int K, int r, float alpha,
-                                                               const float* __restrict__ alpha_dev) {
-  __shared__ float red[8][33];
-  const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
-  const int64_t total = (int64_t)r * K;
-  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int64_t i = (int64_t)blockIdx.x * 32 + e;
-  float s = 0.f;
-  if (i < total) {
-    for (int sp = g; sp < nsplit; sp += 8) s += partial[(int64_t)sp * total + i];
-  }
-  red[g][e] = s;
-  __syncthreads();
-  if (g == 0 && i < total) {
-    float t = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t += red[j][e];
-    const int q = (int)(i / K);
-    const int k = (int)(i - (int64_t)q * K);
-    dW[q * so_r + k * so_k] += a * t;
-  }
-}
-
 // fp32 flat LoRA parameters -> 16-bit GEMM operands, once per forward, for every adapted (possibly fused) GEMM:
 //   downT[rows_pad, K]        = lora_down rows of the site (zero rows up to rows_pad)
 //   upT  [rows_pad, nseg*cs]  block-diagonal: upT[s*r + q][s*cs + n] = lora_up_s[n][q]
@@ -176,6 +82,128 @@ __global__ void lora_prep_kernel(const LoraPrepSite* __restrict__ sites, const f
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped weight-gradient reduction: EVERY rank-r reduction of a backward pass in one launch (per accumulator class).
+//
+// The engine does not launch a reduction per site any more (that was ~700 latency-bound launches per step): each
+// adapted Linear appends jobs to a table while the backward runs -- d(up) = alpha * dY^T xa and d(down) = alpha *
+// dxa^T x, for all segments of a fused projection at once -- and, because the arenas never recycle memory inside a
+// backward, all operands are still there when the dX chain has finished.  Then two launches do everything:
+//   partial: workgroup = (job, M-split, column block); thread = one 16-byte column vector x one of `rpar` row slices,
+//            R x 8 fp32 accumulators; the row slices meet in LDS in a fixed order; partial[split][q][k] is written.
+//   final  : fixed-order sum over the splits, dW (+)= alpha * sum.            No atomics: bit-reproducible.
+// P rows are multiplied by row_scale[m / rows_per_sample] on load (the per-sample loss scale divided out in fp32).
+// Fused projections: column c belongs to segment c / seg_cols and pairs with P columns [seg * r, seg * r + r).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int R>
+__global__ __launch_bounds__(256) void lora_wgrad_grouped_partial_kernel(const WgradJob* __restrict__ jobs, int njobs) {
+  __shared__ float red[256 * 8];
+  __shared__ int jsel;
+  if (threadIdx.x == 0) {  // last job whose first workgroup is <= blockIdx.x (jobs of one class are contiguous)
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].wg0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    jsel = lo;
+  }
+  __syncthreads();
+  const WgradJob jb = jobs[jsel];
+  const int local = blockIdx.x - jb.wg0;
+  const int split = local / jb.ncolblk, colblk = local - split * jb.ncolblk;
+  const int cw = jb.cw;                 // column vectors per workgroup (power of two <= 256)
+  const int rpar = 256 / cw;            // row slices
+  const int tid = threadIdx.x;
+  const int rsub = tid / cw, cl = tid - rsub * cw;
+  const int col8 = colblk * cw + cl;    // this thread's 8-column vector
+  const bool active = col8 * 8 < jb.K;
+  const int row0 = split * jb.rows_per_wg;
+  const int row1 = min(jb.M, row0 + jb.rows_per_wg);
+  const int r = jb.r;
+  const T* X = reinterpret_cast<const T*>(jb.X);
+  const float* P = jb.P + (jb.seg_cols ? ((col8 * 8) / jb.seg_cols) * r : 0);
+  float acc[R][8];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+  if (active) {
+    for (int m0 = row0 + rsub; m0 < row1; m0 += 4 * rpar) {
+      Pack8<T> xv[4];
+      float pv[4][R];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = m0 + u * rpar;
+        const bool ok = m < row1;
+        xv[u].u = ok ? *reinterpret_cast<const u32x4*>(X + (int64_t)m * jb.ldx + col8 * 8) : u32x4{0, 0, 0, 0};
+        const float rs = (ok && jb.row_scale) ? jb.row_scale[m / jb.rows_per_sample] : 1.f;
+#pragma unroll
+        for (int q = 0; q < R; ++q) pv[u][q] = (ok && q < r) ? P[(int64_t)m * jb.ldp + q] * rs : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[q][e] += pv[u][q] * to_f(xv[u].e[e]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (q < r) {  // r is block-uniform: the barriers below are reached by every thread or by none
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(rsub * cw + cl) * 8 + e] = acc[q][e];
+      __syncthreads();
+      if (tid < cw && (colblk * cw + tid) * 8 < jb.K) {
+        float* out = jb.partial + ((int64_t)split * r + q) * jb.K + (colblk * cw + tid) * 8;
+        float sum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+        for (int rs = 0; rs < rpar; ++rs)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum[e] += red[(rs * cw + tid) * 8 + e];
+        *reinterpret_cast<f32x4*>(out) = f32x4{sum[0], sum[1], sum[2], sum[3]};
+        *reinterpret_cast<f32x4*>(out + 4) = f32x4{sum[4], sum[5], sum[6], sum[7]};
+      }
+    }
+  }
+}
+
+// block = 32 consecutive outputs x 8 split-groups (group g sums splits g, g+8, ... in order; LDS combines the groups
+// in order): deterministic.  dW[q*so_r + k*so_k] += alpha * sum.
+__global__ __launch_bounds__(256) void lora_wgrad_grouped_final_kernel(const WgradJob* __restrict__ jobs, int njobs) {
+  __shared__ float red[8][33];
+  __shared__ int jsel;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].fb0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    jsel = lo;
+  }
+  __syncthreads();
+  const WgradJob jb = jobs[jsel];
+  const int64_t total = (int64_t)jb.r * jb.K;
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t i = (int64_t)(blockIdx.x - jb.fb0) * 32 + e;
+  float s = 0.f;
+  if (i < total) {
+    for (int sp = g; sp < jb.nsplit; sp += 8) s += jb.partial[(int64_t)sp * total + i];
+  }
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][e];
+    const int q = (int)(i / jb.K);
+    const int k = (int)(i - (int64_t)q * jb.K);
+    jb.dW[q * jb.so_r + k * jb.so_k] += jb.alpha * t;
+  }
+}
+
 template <typename T>
 int down_t(const void* X, int64_t ldx, const float* A, int64_t sr, int64_t sk, float* xa, int64_t ld_xa, int M, int K,
            int r, hipStream_t st) {
@@ -190,26 +218,6 @@ int down_t(const void* X, int64_t ldx, const float* A, int64_t sr, int64_t sk, f
   return 0;
 }
 
-template <typename T>
-int wgrad_t(const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r, int64_t so_k, int M, int K, int r,
-            float alpha, const float* alpha_dev, float* scratch, hipStream_t st) {
-  const int nsplit = cdiv(M, wg_rows(M));
-  const int cols8 = K / 8;
-  dim3 grid(nsplit, cdiv(cols8, 256));
-  const size_t sm = 256 * 8 * sizeof(float);
-#define L(RR) hipLaunchKernelGGL((lora_wgrad_partial_kernel<T, RR>), grid, dim3(256), sm, st, P, ldp, (const T*)X, ldx, scratch, M, K, r)
-  if (r <= 4) L(4);
-  else if (r <= 8) L(8);
-  else if (r <= 16) L(16);
-  else L(32);
-#undef L
-  const int64_t total = (int64_t)r * K;
-  hipLaunchKernelGGL(lora_wgrad_final_kernel, dim3((int)((total + 31) / 32)), dim3(256), 0, st, scratch, nsplit, dW,
-                     so_r, so_k, K, r, alpha, alpha_dev);
-  SMI_HIP(hipGetLastError());
-  return 0;
-}
-
 }  // namespace
 
 int launch_lora_down(int dtype, const void* X, int64_t ldx, const float* A, int64_t lda_r, int64_t lda_k, float* xa,
@@ -217,17 +225,6 @@ int launch_lora_down(int dtype, const void* X, int64_t ldx, const float* A, int6
   SMI_CHECK(r >= 1 && r <= 32 && K % 8 == 0 && ldx % 8 == 0, "lora_down: r=%d K=%d ldx=%lld", r, K, (long long)ldx);
   return dtype == DT_F16 ? down_t<f16>(X, ldx, A, lda_r, lda_k, xa, ld_xa, M, K, r, stream)
                          : down_t<bf16>(X, ldx, A, lda_r, lda_k, xa, ld_xa, M, K, r, stream);
-}
-
-// scratch: lora_wgrad_scratch_floats(M, K, r) floats
-size_t lora_wgrad_scratch_floats(int M, int K, int r) { return (size_t)cdiv(M, wg_rows(M)) * r * K; }
-
-int launch_lora_wgrad(int dtype, const float* P, int64_t ldp, const void* X, int64_t ldx, float* dW, int64_t so_r,
-                      int64_t so_k, int M, int K, int r, float alpha, const float* alpha_dev, float* scratch,
-                      hipStream_t stream) {
-  SMI_CHECK(r >= 1 && r <= 32 && K % 8 == 0 && ldx % 8 == 0, "lora_wgrad: r=%d K=%d", r, K);
-  return dtype == DT_F16 ? wgrad_t<f16>(P, ldp, X, ldx, dW, so_r, so_k, M, K, r, alpha, alpha_dev, scratch, stream)
-                         : wgrad_t<bf16>(P, ldp, X, ldx, dW, so_r, so_k, M, K, r, alpha, alpha_dev, scratch, stream);
 }
 
 int launch_lora_prep(int dtype, const void* sites_dev, int n_sites, const float* down, const float* up, void* shadow,
@@ -329,6 +326,79 @@ int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, flo
     if (R == 16) GO(bf16, 1); else GO(bf16, 2);
   }
 #undef GO
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// Fills the launch geometry of one job (host): column-block width, M-split, scratch need.
+void wgrad_job_plan(WgradJob& j) {
+  const int cols8 = j.K / 8;
+  int cw = 256;
+  while (cw > 16 && cols8 % cw != 0) cw >>= 1;  // largest power of two (16..256) dividing the vector count
+  if (cols8 % cw != 0) {                        // none does: one power-of-two block >= the count (tail lanes idle)
+    cw = 1;
+    while (cw < cols8 && cw < 256) cw <<= 1;
+  }
+  j.cw = cw;
+  j.ncolblk = cdiv(cols8, cw);
+  j.rows_per_wg = j.M >= 8192 ? 128 : 64;
+  j.nsplit = cdiv(j.M, j.rows_per_wg);
+}
+size_t wgrad_job_scratch_floats(const WgradJob& j) { return (size_t)j.nsplit * j.r * j.K; }
+
+// jobs_host: the table as the device will see it (wg0 / fb0 filled here); jobs_dev: its device copy.  Jobs must be
+// sorted by accumulator class (r <= 4, <= 8, <= 16, <= 32): one partial launch per class present, one final launch.
+int wgrad_grouped_finish(std::vector<WgradJob>& jobs) {
+  std::stable_sort(jobs.begin(), jobs.end(), [](const WgradJob& a, const WgradJob& b) {
+    auto cls = [](int r) { return r <= 4 ? 0 : r <= 8 ? 1 : r <= 16 ? 2 : 3; };
+    return cls(a.r) < cls(b.r);
+  });
+  int fb = 0;
+  int cur_cls = -1, wg = 0;
+  for (auto& j : jobs) {
+    const int c = j.r <= 4 ? 0 : j.r <= 8 ? 1 : j.r <= 16 ? 2 : 3;
+    if (c != cur_cls) {
+      cur_cls = c;
+      wg = 0;
+    }
+    j.wg0 = wg;
+    wg += j.nsplit * j.ncolblk;
+    j.fb0 = fb;
+    fb += (int)(((int64_t)j.r * j.K + 31) / 32);
+  }
+  return 0;
+}
+
+int launch_lora_wgrad_grouped(int dtype, const std::vector<WgradJob>& jobs, const WgradJob* jobs_dev,
+                              hipStream_t stream) {
+  if (jobs.empty()) return 0;
+  size_t i = 0;
+  int final_blocks = 0;
+  while (i < jobs.size()) {
+    auto cls = [](int r) { return r <= 4 ? 0 : r <= 8 ? 1 : r <= 16 ? 2 : 3; };
+    const int c = cls(jobs[i].r);
+    size_t k = i;
+    int wgs = 0;
+    while (k < jobs.size() && cls(jobs[k].r) == c) {
+      SMI_CHECK(jobs[k].r >= 1 && jobs[k].r <= 32 && jobs[k].K % 8 == 0 && jobs[k].ldx % 8 == 0,
+                "lora_wgrad: r=%d K=%d", jobs[k].r, jobs[k].K);
+      wgs += jobs[k].nsplit * jobs[k].ncolblk;
+      final_blocks += (int)(((int64_t)jobs[k].r * jobs[k].K + 31) / 32);
+      ++k;
+    }
+    const int n = (int)(k - i);
+#define L(TT_, RR) hipLaunchKernelGGL((lora_wgrad_grouped_partial_kernel<TT_, RR>), dim3(wgs), dim3(256), 0, stream, jobs_dev + i, n)
+    if (dtype == DT_F16) {
+      if (c == 0) L(f16, 4); else if (c == 1) L(f16, 8); else if (c == 2) L(f16, 16); else L(f16, 32);
+    } else {
+      if (c == 0) L(bf16, 4); else if (c == 1) L(bf16, 8); else if (c == 2) L(bf16, 16); else L(bf16, 32);
+    }
+#undef L
+    i = k;
+  }
+  hipLaunchKernelGGL(lora_wgrad_grouped_final_kernel, dim3(final_blocks), dim3(256), 0, stream, jobs_dev,
+                     (int)jobs.size());
   SMI_HIP(hipGetLastError());
   return 0;
 }

@@ -49,10 +49,16 @@ def _text_step(rank, world, global_b=2, steps=2):
     tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]])
     lat = torch.randn(global_b, 4, 16, 16, generator=torch.Generator().manual_seed(3))
     local = lat[parallel.shard_slice(global_b, rank, world)].cuda()
-    step = SliderStep(pu, net, sched, lr=1e-3, weight_decay=1e-6, max_grad_norm=0.2)
+    # Adam eps >> |gradient|: the update is proportional to the gradient, so fp32 reduction-order differences are not
+    # amplified into the second step (with eps = 1e-8 the first steps are sign-like)
+    step = SliderStep(pu, net, sched, lr=1e-3, weight_decay=1e-6, max_grad_norm=0.2, eps=1e-3)
     cond = step.make_conditioning(emb, local.shape[0], pooled, tid)
-    losses = [float(step.train_step(local, t, cond, "enhance", 2.0).item()) for _ in range(steps)]
-    return {"losses": torch.tensor(losses), "grad": step.grad.cpu(), "flat": net.flat.detach().cpu()}
+    losses, grad1 = [], None
+    for i in range(steps):
+        losses.append(float(step.train_step(local, t, cond, "enhance", 2.0).item()))
+        if i == 0:
+            grad1 = step.grad.cpu().clone()  # all-reduced gradient of the FIRST step: same parameters on both sides
+    return {"losses": torch.tensor(losses), "grad": grad1, "flat": net.flat.detach().cpu()}
 
 
 def _image_step(rank, world, pairs=2):
