@@ -53,8 +53,15 @@ class LoRAModuleRef(nn.Module):
         return self.org_forward(x) + self.lora_up(self.lora_down(x)) * self.multiplier * self.scale
 
 
-def select_lora_targets(unet: nn.Module, train_method: str, target_replace=("Attention",), prefix="lora_unet"):
-    """Name/class-name walk of T/lora.py:194-251.  Returns [(lora_name, module_path, child_module)]."""
+C3LIER_TARGET_REPLACE = ("Attention", "ResnetBlock2D", "Downsample2D", "Upsample2D", "DownBlock2D", "UpBlock2D")
+"""T/lora.py:14-26 after T/train_lora.py:44-46 (`network.type: c3lier`)."""
+
+
+def select_lora_targets(unet: nn.Module, train_method: str, target_replace=("Attention",), prefix="lora_unet",
+                        with_duplicates=False):
+    """Name/class-name walk of T/lora.py:194-251.  Returns [(lora_name, module_path, child_module)]; with
+    `with_duplicates` also the second visits of a name (the reference builds a LoRAModule for those too and then
+    drops it, T/lora.py:243-249), as 4-tuples ending in True."""
     out, names = [], []
     for name, module in unet.named_modules():
         if train_method in ("noxattn", "noxattn-hspace", "noxattn-hspace-last"):
@@ -88,7 +95,9 @@ def select_lora_targets(unet: nn.Module, train_method: str, target_replace=("Att
                     lora_name = (prefix + "." + name + "." + child_name).replace(".", "_")
                     if lora_name not in names:
                         names.append(lora_name)
-                        out.append((lora_name, name + "." + child_name, child))
+                        out.append((lora_name, name + "." + child_name, child) + ((False,) if with_duplicates else ()))
+                    elif with_duplicates:
+                        out.append((lora_name, name + "." + child_name, child, True))
     return out
 
 
@@ -100,8 +109,11 @@ class LoRANetworkRef(nn.Module):
         self.lora_dim = rank
         self.alpha = alpha
         self.unet_loras: List[LoRAModuleRef] = []
-        for lora_name, _path, child in select_lora_targets(unet, train_method, target_replace):
-            self.unet_loras.append(LoRAModuleRef(lora_name, child, multiplier, rank, alpha))
+        for lora_name, _path, child, dup in select_lora_targets(unet, train_method, target_replace,
+                                                                with_duplicates=True):
+            m = LoRAModuleRef(lora_name, child, multiplier, rank, alpha)  # built (RNG consumed) even when dropped
+            if not dup:
+                self.unet_loras.append(m)
         assert len({l.lora_name for l in self.unet_loras}) == len(self.unet_loras)
         for lora in self.unet_loras:
             lora.apply_to()

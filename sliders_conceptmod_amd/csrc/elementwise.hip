@@ -144,6 +144,39 @@ __global__ void pool2x2_sum_kernel(const T* __restrict__ du, T* __restrict__ dx,
   }
 }
 
+// out[n][c] = mul * sum_{hw} x[n][hw][c]  (gradient of a per-sample row vector added to every pixel: the time-embedding
+// projection under a c3lier adaptor).  One workgroup per (64-column block, sample); its 4 waves split the rows, each lane
+// owns one column; fixed-order combine through LDS: deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, T* __restrict__ out, int HW, int C,
+                                                     float mul) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C) {
+    const T* p = x + (int64_t)n * HW * C + c;
+    for (int r = w; r < HW; r += 4) acc += to_f(p[(int64_t)r * C]);
+  }
+  red[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+    out[(int64_t)n * C + c] = from_f<T>(((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * mul);
+  }
+}
+// dst[m][0..cpad) = (T)(src[m][0..cols) * mul), zero beyond cols   (fp32 rank-r rows -> a 64-channel MFMA operand)
+template <typename T>
+__global__ void f32_to_padded_kernel(const float* __restrict__ src, int lds, int cols, T* __restrict__ dst, int cpad,
+                                     int64_t M, float mul) {
+  GSTRIDE(i, M * cpad) {
+    const int c = (int)(i % cpad);
+    const int64_t m = i / cpad;
+    dst[i] = from_f<T>(c < cols ? src[m * lds + c] * mul : 0.f);
+  }
+}
+
 // ---- reductions to a scalar: block partials into scratch, last-stage by one block (deterministic order)
 template <int OP>  // 0: max|x|   1: sum x^2
 __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ x, int64_t n,
@@ -402,6 +435,26 @@ int launch_clip_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 int launch_sched_affine(float* x, const float* eps, const float* noise, float c_x, float c_eps, float c_noise,
                         int64_t n, hipStream_t stream) {
   hipLaunchKernelGGL(sched_affine_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, eps, noise, c_x, c_eps, c_noise, n);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_colsum(int dtype, const void* x, void* out, int Nb, int HW, int C, float mul, hipStream_t stream) {
+  dim3 grid(cdiv(C, 64), Nb);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)x, (f16*)out, HW, C, mul);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)x, (bf16*)out, HW, C, mul);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_f32_to_padded(int dtype, const float* src, int lds, int cols, void* dst, int cpad, int64_t M, float mul,
+                         hipStream_t stream) {
+  const int grid = ew_grid(M * cpad);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(f32_to_padded_kernel<f16>, dim3(grid), dim3(256), 0, stream, src, lds, cols, (f16*)dst, cpad, M, mul);
+  else
+    hipLaunchKernelGGL(f32_to_padded_kernel<bf16>, dim3(grid), dim3(256), 0, stream, src, lds, cols, (bf16*)dst, cpad, M, mul);
   SMI_HIP(hipGetLastError());
   return 0;
 }

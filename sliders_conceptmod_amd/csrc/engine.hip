@@ -116,6 +116,7 @@ struct Ten {
   // differentiated) samples last; gradients `g` cover rows [arow0, rows) only
   int64_t arow0 = 0;
   bool ng = false;
+  float gmul = 1.f;  // the stored gradient g is gmul x the (loss-scaled) gradient; a power of two, 1 but for row vectors
 };
 
 struct Lin {
@@ -141,6 +142,14 @@ struct Conv {
   const void* b = nullptr;
   int Cin = 0, Cout = 0;
   int mode = 0;  // 0 stride 1, 1 stride-2 downsample, 2 nearest-2x upsample + conv
+  // c3lier LoRA (T/lora.py:100-114): 3x3 down conv [r][Cin][3][3] with the layer's stride / padding, then 1x1 up [Cout][r]
+  std::string name;
+  int nsite = 0, rank = 0, rows_pad = 0;
+  float scale = 0.f;
+  int64_t off_down = 0, off_up = 0;
+  const void* sh_down = nullptr;  // 16-bit [rows_pad][9*Cin], (ky,kx,ci)-ordered: filter of the xa conv
+  const void* sh_up = nullptr;    // 16-bit [rows_pad][Cout] = up^T (dxa = dy * up)
+  const void* sh_gw = nullptr;    // 16-bit [Cin][9*64]: gradient filter of the down conv, rank zero-padded to 64
 };
 struct Norm {
   const void* gamma = nullptr;
@@ -192,6 +201,30 @@ struct smi_engine {
   WgradJob* wjobs_dev = nullptr;
   size_t wjobs_cap = 0;
   std::vector<const void*> pinned;
+  WgradJob& push_wjob(const void* X, int64_t ldx, const float* P, int64_t ldp, float* dW, int64_t so_r, int64_t so_k,
+                      int M, int K, int rr, int seg_cols, int rows_per_sample, float alpha) {
+    WgradJob j;
+    memset(&j, 0, sizeof(j));  // padding too: the table is compared bytewise with the uploaded copy
+    j.X = X;
+    j.ldx = ldx;
+    j.P = P;
+    j.ldp = ldp;
+    j.dW = dW;
+    j.so_r = so_r;
+    j.so_k = so_k;
+    j.M = M;
+    j.K = K;
+    j.r = rr;
+    j.seg_cols = seg_cols;
+    j.rows_per_sample = rows_per_sample;
+    j.row_scale = gscale + MAXS;
+    j.alpha = alpha;
+    j.conv_tap = -1;
+    wgrad_job_plan(j);
+    j.partial = alloc_f32(wgrad_job_scratch_floats(j));
+    wjobs.push_back(j);
+    return wjobs.back();
+  }
   bool is_pinned(const void* g) const {
     for (const void* q : pinned)
       if (q == g) return true;
@@ -504,7 +537,7 @@ struct smi_engine {
     L.off_up = first->off_up;
     const int rtot = L.rank * L.nseg;
     L.rows_pad = (rtot + 15) / 16 * 16;
-    HostLoraPrepSite ps;
+    HostLoraPrepSite ps{};
     ps.off_down = L.off_down;
     ps.off_up = L.off_up;
     ps.dst_down = (int64_t)lora_shadow_elems;
@@ -520,6 +553,42 @@ struct smi_engine {
     L.sh_down = reinterpret_cast<const void*>((uintptr_t)ps.dst_down);  // offsets for now; rebased in finish_lora()
     L.sh_up = reinterpret_cast<const void*>((uintptr_t)ps.dst_up);
   }
+  void attach_lora_conv(Conv& c) {
+    auto it = smap.find(c.name);
+    if (it == smap.end()) return;
+    const smi_lora_site* s = it->second;
+    site_used[s - sites.data()] = 1;
+    c.nsite = 1;
+    c.rank = s->rank;
+    c.scale = s->scale;
+    c.off_down = s->off_down;
+    c.off_up = s->off_up;
+    c.rows_pad = (c.rank + 15) / 16 * 16;
+    if (c.rank > 64) {
+      set_error("conv LoRA rank %d > 64 on '%s'", c.rank, c.name.c_str());
+      err = true;
+      return;
+    }
+    HostLoraPrepSite ps{};
+    ps.off_down = c.off_down;
+    ps.off_up = c.off_up;
+    ps.dst_down = (int64_t)lora_shadow_elems;
+    lora_shadow_elems += (size_t)c.rows_pad * 9 * c.Cin;
+    ps.dst_up = (int64_t)lora_shadow_elems;
+    lora_shadow_elems += (size_t)c.rows_pad * c.Cout;
+    ps.dst_gw = (int64_t)lora_shadow_elems;
+    lora_shadow_elems += (size_t)c.Cin * 9 * 64;
+    ps.r = c.rank;
+    ps.nseg = 1;
+    ps.K = c.Cin;
+    ps.cs = c.Cout;
+    ps.rows_pad = c.rows_pad;
+    ps.conv = c.mode == 1 ? 2 : 1;  // 1: flipped taps in the gradient filter, 2: stride-2 (unflipped, transposed gather)
+    prep_sites.push_back(ps);
+    c.sh_down = reinterpret_cast<const void*>((uintptr_t)ps.dst_down);
+    c.sh_up = reinterpret_cast<const void*>((uintptr_t)ps.dst_up);
+    c.sh_gw = reinterpret_cast<const void*>((uintptr_t)ps.dst_gw);
+  }
   void finish_lora() {  // after build(): all Lin objects are at their final addresses
     lora_shadow = (char*)pack_alloc(std::max<size_t>(lora_shadow_elems, 8) * esz());
     prep_sites_dev = pack_alloc(std::max<size_t>(prep_sites.size(), 1) * sizeof(HostLoraPrepSite));
@@ -530,7 +599,8 @@ struct smi_engine {
   const void* shadow_ptr(const void* off) const { return lora_shadow + (uintptr_t)off * 2; }
 
   // need_t: the layer lies on the gradient path (gets a transposed copy) and may carry a LoRA adaptor
-  Lin make_lin(const std::string& name, int in, int out, bool bias, bool need_t = true) {
+  // attach_only: the layer may carry a LoRA adaptor although no gradient flows to its input (time_emb_proj)
+  Lin make_lin(const std::string& name, int in, int out, bool bias, bool need_t = true, bool attach_only = false) {
     Lin L;
     L.name = name;
     L.in = in;
@@ -542,6 +612,8 @@ struct smi_engine {
       void* t = pack_alloc((size_t)in * out * esz());
       transpose_into(L.W, t, out, in, out, 0);
       L.Wt = t;
+      attach_lora(L, {name});
+    } else if (attach_only) {
       attach_lora(L, {name});
     }
     return L;
@@ -577,7 +649,9 @@ struct smi_engine {
     c.Cout = Cout;
     c.mode = mode;
     c.b = Wd(name + ".bias");
+    c.name = name;
     check_shape(name + ".weight", {Cout, Cin, 3, 3});
+    attach_lora_conv(c);
     void* wp = pack_alloc((size_t)Cout * Cin * 9 * esz());
     pack_conv_into(Wd(name + ".weight"), wp, Cout, Cin, 0);
     c.Wp = wp;
@@ -602,7 +676,7 @@ struct smi_engine {
     const int ted = cfg.block_out_channels[0] * 4;
     r.n1 = make_norm(name + ".norm1", Cin, 1e-5f);
     r.c1 = make_conv(name + ".conv1", Cin, Cout, 0, true);
-    r.temb = make_lin(name + ".time_emb_proj", ted, Cout, true, false);
+    r.temb = make_lin(name + ".time_emb_proj", ted, Cout, true, false, true);
     r.n2 = make_norm(name + ".norm2", Cout, 1e-5f);
     r.c2 = make_conv(name + ".conv2", Cout, Cout, 0, true);
     r.has_sc = Cin != Cout;
@@ -709,11 +783,12 @@ struct smi_engine {
     build_kv_group();
     finish_lora();
     gscale = (float*)pack_alloc((2 * MAXS + 256) * sizeof(float));
-    wjobs_cap = 2 * (sites.size() + 8);
+    wjobs_cap = 11 * (sites.size() + 8);  // a conv site pushes 10 jobs (d_up + one d_down job per filter tap)
     wjobs_dev = (WgradJob*)pack_alloc(wjobs_cap * sizeof(WgradJob));
     for (size_t i = 0; i < sites.size(); ++i)
       if (!site_used[i] && !err) {
-        set_error("LoRA target '%s' is not an attention projection this engine adapts (lierla/attention-only)",
+        set_error("LoRA target '%s' is not a layer this engine adapts (attention projections; with c3lier: resnet "
+                  "conv1 / conv2 / time_emb_proj / conv_shortcut and the up / down sampler convs)",
                   site_names[i].c_str());
         err = true;
       }
@@ -849,26 +924,11 @@ struct smi_engine {
       // deferred (see `wjobs`): d(up)[n][q] += lscale/S * sum_m dy[m][n] * xa[m][seg(n)*r + q]  for all segments,
       //                         d(down)[q'][k] += lscale/S * sum_m dxa[m][q'] * x[m][k]       (q' over the r_tot rows)
       const int rps = (int)(M / std::max(n_ad, 1));
+      const float alpha = lscale / y->gmul;  // y->gmul: power-of-two factor the stored gradient carries (1 but for row vectors)
       auto push = [&](const void* X, int64_t ldx, const float* P, float* dW, int64_t so_r, int64_t so_k, int K, int rr,
                       int seg_cols) {
-        WgradJob j{};
-        j.X = X;
-        j.ldx = ldx;
-        j.P = P;
-        j.ldp = rp;
-        j.dW = dW;
-        j.so_r = so_r;
-        j.so_k = so_k;
-        j.M = M;
-        j.K = K;
-        j.r = rr;
-        j.seg_cols = seg_cols;
-        j.rows_per_sample = rps;
-        j.row_scale = gscale + MAXS;
-        j.alpha = lscale;
-        wgrad_job_plan(j);
-        j.partial = alloc_f32(wgrad_job_scratch_floats(j));
-        wjobs.push_back(j);
+        WgradJob& j = push_wjob(X, ldx, P, rp, dW, so_r, so_k, M, K, rr, seg_cols, rps, alpha);
+        (void)j;
       };
       push(dy, L->out, xa, d_up ? d_up + L->off_up : nullptr, 1, r, L->out, r, L->nseg > 1 ? cs : 0);
       if (rtot <= 32) {
@@ -949,7 +1009,7 @@ struct smi_engine {
       tape.push_back([=]() {
         if (!y->g) return;
         const Slot gs = grad_slot(x);
-        float* scr = alloc_f32(npart + (size_t)2 * x->n * C);
+        float* scr = alloc_f32(npart);
         const int n0 = (int)(x->arow0 / HW);  // first adapted sample
         RUNP(SMI_PROF_NORM, 0.0, 6.0 * MA(x) * x->cols, launch_groupnorm_bwd(dtype, PA(x), y->g, np->gamma, np->beta, ab + (size_t)n0 * C, ab + (size_t)(x->n + n0) * C, mr + (size_t)n0 * G * 2, gs.add, gs.out, scr, x->n - n0, HW,
                                  C, G, silu ? 1 : 0, stream));
@@ -1130,17 +1190,113 @@ struct smi_engine {
       p.res = res->p;
       p.ldr = res->cols;
     }
+    // c3lier adaptor: y += lscale * up(down_conv(x)) on the adapted samples.  xa = down_conv(x) is one more implicit-GEMM
+    // conv with the (16-row padded) shadow filter and fp32 output; the 1x1 up-projection rides in the main epilogue.
+    const bool lon = c.nsite > 0 && (dry || (lora_down && lora_up && mult != 0.f));
+    const float lscale = mult * c.scale;
+    float* xa = nullptr;
+    if (lon) {
+      xa = alloc_f32((size_t)MA(y) * c.rows_pad);
+      GemmParams g = p;
+      g.A = PA(x);
+      g.W = shadow_ptr(c.sh_down);
+      g.C = xa;
+      g.ldc = c.rows_pad;
+      g.out_f32 = 1;
+      g.M = (int)MA(y);
+      g.N = c.rows_pad;
+      g.bias = nullptr;
+      g.rowvec = nullptr;
+      g.res = nullptr;
+      g.Nb = x->n - (int)(x->arow0 / (Hin * Win));
+      RUNP(SMI_PROF_LORA, 2.0 * g.M * c.rank * g.K, 0.0, launch_gemm(g, stream));
+      p.lora_xa = xa;
+      p.ld_xa = c.rows_pad;
+      p.lora_up = lora_up + c.off_up;
+      p.up_sn = c.rank;
+      p.up_sq = 1;
+      p.lora_r = c.rank;
+      p.lora_seg = 0;
+      p.lora_scale = lscale;
+      p.lora_row0 = (int)y->arow0;
+    }
     RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 2.0 * ((double)x->rows * c.Cin + (double)p.N * p.K + (double)p.M * p.N),
          (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
-    y->ng = x->ng || (res && res->ng);
+    y->ng = lon || x->ng || (res && res->ng) || (rowvec && rowvec->ng);
     if (saving && y->ng) {
       const Conv* cp = &c;
       tape.push_back([=]() {
         void* dy = y->g;
         if (!dy) return;
         if (res && res->ng) accumulate(res, dy);
+        const int nb_ad = x->n - (int)(x->arow0 / (Hin * Win));  // adapted samples
+        if (rowvec && rowvec->ng) {
+          // d(rowvec)[n][c] = sum over the pixels of sample n of dy; stored x 2^-k (k ~ log2(HW) / 2) so that a coherent sum
+          // cannot leave the fp16 range -- linear_bwd divides it out again (Ten::gmul)
+          int k = 0;
+          while ((1 << (2 * (k + 1))) <= Hout * Wout) ++k;
+          rowvec->gmul = exp2f((float)-k);
+          rowvec->g = alloc_t(MA(rowvec), rowvec->cols);
+          RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_colsum(dtype, dy, rowvec->g, nb_ad, Hout * Wout, cp->Cout, rowvec->gmul, stream));
+        }
+        float* dxa = nullptr;
+        if (lon) {
+          const int M = (int)MA(y), rp = cp->rows_pad, r = cp->rank;
+          dxa = alloc_f32((size_t)M * rp);
+          {  // dxa[M, rows_pad] = dy * up
+            GemmParams g;
+            g.dtype = dtype;
+            g.A = dy;
+            g.lda = cp->Cout;
+            g.W = shadow_ptr(cp->sh_up);
+            g.C = dxa;
+            g.ldc = rp;
+            g.out_f32 = 1;
+            g.M = M;
+            g.N = rp;
+            g.K = cp->Cout;
+            if (dry || lora_skinny_supported(g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K))
+              RUNP(SMI_PROF_LORA, 2.0 * M * r * cp->Cout, 0.0,
+                   launch_lora_skinny(dtype, g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K, stream));
+            else
+              RUNP(SMI_PROF_LORA, 2.0 * M * r * cp->Cout, 0.0, launch_gemm(g, stream));
+          }
+          const int rps = Hout * Wout;
+          // d(up)[n][q] += lscale/S * sum_m dy[m][n] xa[m][q];  d(down)[q][ci][tap] += lscale/S * sum_m dxa[m][q] x[pixel(m, tap)][ci]
+          push_wjob(dy, cp->Cout, xa, rp, d_up ? d_up + cp->off_up : nullptr, 1, r, M, cp->Cout, r, 0, rps, lscale);
+          for (int t = 0; t < 9; ++t) {
+            WgradJob& j = push_wjob(PA(x), cp->Cin, dxa, rp, d_down ? d_down + cp->off_down + t : nullptr,
+                                    (int64_t)9 * cp->Cin, 9, M, cp->Cin, r, 0, rps, lscale);
+            j.conv_tap = t;
+            j.Hin = Hin;
+            j.Win = Win;
+            j.Hout = Hout;
+            j.Wout = Wout;
+            j.conv_stride = cp->mode == 1 ? 2 : 1;
+            j.conv_ups = cp->mode == 2 ? 1 : 0;
+          }
+          pinned.push_back(dy);
+        }
         if (!x->ng) return;
         const Slot gs = grad_slot(x);
+        // the adaptor's share of dX: the same gradient conv once more on dxa (fp32 -> 64-channel 16-bit image, x lscale)
+        // with the down filter's gradient pack, accumulated onto the main result
+        void* dxa16 = nullptr;
+        if (lon) {
+          dxa16 = alloc_t(MA(y), 64);
+          RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_f32_to_padded(dtype, dxa, cp->rows_pad, cp->rank, dxa16, 64, MA(y), lscale, stream));
+        }
+        auto lora_dx = [&](GemmParams b, void* acc) {  // b: the main gradient conv's parameters
+          if (!lon) return;
+          b.A = dxa16;
+          b.W = shadow_ptr(cp->sh_gw);
+          b.K = 9 * 64;
+          b.Cin = 64;
+          b.C = acc;
+          b.res = acc;
+          b.ldr = cp->Cin;
+          RUNP(SMI_PROF_LORA, 2.0 * b.M * b.N * 9 * cp->rank, 0.0, launch_gemm(b, stream));
+        };
         GemmParams b;
         b.dtype = dtype;
         b.conv = 1;
@@ -1161,6 +1317,7 @@ struct smi_engine {
             b.ldr = cp->Cin;
           }
           RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(b), 0) : 0, launch_gemm(b, stream)));
+          lora_dx(b, gs.out);
         } else if (cp->mode == 1) {  // gradient of the stride-2 conv: gather dY at (i + 1 - k) / 2
           b.Hin = Hout;
           b.Win = Wout;
@@ -1175,6 +1332,7 @@ struct smi_engine {
             b.ldr = cp->Cin;
           }
           RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(b), 0) : 0, launch_gemm(b, stream)));
+          lora_dx(b, gs.out);
         } else {  // upsample + conv: gradient on the 2x grid, then 2x2 sum-pool
           void* du = alloc_t(MA(y), cp->Cin);
           b.Hin = b.Hout = Hout;
@@ -1182,6 +1340,7 @@ struct smi_engine {
           b.M = (int)MA(y);
           b.C = du;
           RUNP(SMI_PROF_CONV, 2.0 * b.M * b.N * b.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(b), 0) : 0, launch_gemm(b, stream)));
+          lora_dx(b, du);
           if (gs.add) {
             void* tmp = alloc_t(MA(x), cp->Cin);
             RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_pool2x2_sum(dtype, du, tmp, b.Nb, Hin, Win, cp->Cin, stream));
@@ -1290,20 +1449,20 @@ struct smi_engine {
     // ---- time / added-condition embedding (no gradient flows here: not adapted under lierla)
     float* tvals = alloc_f32(n);
     if (!dry && !err) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, stream, tvals, timestep, n);
-    Ten* te = new_ten(n, C0);
+    Ten* te = new_ten(n, C0, n, 1, 1);  // [n, C] tensors carry n, H = W = 1: the adapted samples are the last rows
     RUN(launch_timestep_embed(dtype, tvals, te->p, n, C0, stream));
     Ten* emb = linear(silu(linear(te, time1)), time2);
     if (cfg.addition_embed) {
       const int P = cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim;
-      Ten* tid = new_ten(n, 6 * cfg.addition_time_embed_dim);
+      Ten* tid = new_ten(n, 6 * cfg.addition_time_embed_dim, n, 1, 1);
       RUN(launch_timestep_embed(dtype, time_ids, tid->p, n * 6, cfg.addition_time_embed_dim, stream));
-      Ten* cat = new_ten(n, cfg.projection_class_embeddings_input_dim);
+      Ten* cat = new_ten(n, cfg.projection_class_embeddings_input_dim, n, 1, 1);
       Ten pooled;
       pooled.p = const_cast<void*>(text_embeds);
       RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, pooled.p, P, cat->p, cat->cols, 0, n, P, stream));
       RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, tid->p, tid->cols, cat->p, cat->cols, P, n, tid->cols, stream));
       Ten* aug = linear(silu(linear(cat, add1)), add2);
-      Ten* sum = new_ten(n, ted);
+      Ten* sum = new_ten(n, ted, n, 1, 1);
       RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_add(dtype, emb->p, aug->p, sum->p, (int64_t)n * ted, stream));
       emb = sum;
     }
@@ -1904,7 +2063,8 @@ int smi_op_lora_wgrad(int dtype, const float* p, const void* x, float* dw, int m
   // the engine's grouped reduction with a one-job table (scratch: the job's partials followed by the table itself)
   std::vector<WgradJob> jobs(1);
   WgradJob& j = jobs[0];
-  j = WgradJob{};
+  memset(&j, 0, sizeof(j));
+  j.conv_tap = -1;
   j.X = x;
   j.ldx = k;
   j.P = p;

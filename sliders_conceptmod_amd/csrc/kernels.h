@@ -124,6 +124,11 @@ int launch_nhwc_to_nchw_f32(const float* src, float* dst, int Nb, int C, int HW,
 int launch_timestep_embed(int dtype, const float* vals, void* out, int n, int dim, hipStream_t stream);
 // dx[n,h,w,c] = sum_{2x2} du[n,2h+a,2w+b,c]
 int launch_pool2x2_sum(int dtype, const void* du, void* dx, int Nb, int H, int W, int C, hipStream_t stream);
+// out[n][c] = mul * sum over the HW rows of sample n of x[n][hw][c]   (deterministic)
+int launch_colsum(int dtype, const void* x, void* out, int Nb, int HW, int C, float mul, hipStream_t stream);
+// dst[M][cpad] (T) = src[M][0..cols) (fp32, row stride lds) * mul, zero padded
+int launch_f32_to_padded(int dtype, const float* src, int lds, int cols, void* dst, int cpad, int64_t M, float mul,
+                         hipStream_t stream);
 // power-of-two loss scales chosen on device, ONE PER SAMPLE, from max|d_eps[sample]| (keeps 16-bit activation
 // gradients in range and makes a sample's backward independent of its batch mates):
 // scale_out[j] = scale, scale_out[inv_off + j] = 1 / scale
@@ -147,6 +152,9 @@ struct WgradJob {
   int64_t ldx, ldp, so_r, so_k;
   int M, K, r, seg_cols, rows_per_sample;
   float alpha;
+  // conv_tap >= 0: X is an image [n][Hin][Win][K] and row m = (n, oy, ox) of the OUTPUT grid reads the input pixel of
+  // filter tap (ky, kx) = (conv_tap / 3, conv_tap % 3) of a 3x3 / pad-1 conv (zero outside): the k x k LoRA down filter
+  int conv_tap, Hin, Win, Hout, Wout, conv_stride, conv_ups;
   int cw, ncolblk, rows_per_wg, nsplit;  // geometry (wgrad_job_plan)
   int wg0, fb0;                          // first workgroup in the partial / final grid (wgrad_grouped_finish)
 };
@@ -156,6 +164,10 @@ size_t wgrad_job_scratch_floats(const WgradJob& j);
 struct HostLoraPrepSite {
   int64_t off_down, off_up, dst_down, dst_up;
   int r, nseg, K, cs, rows_pad;
+  // conv site (c3lier): 0 = Linear; 1 / 2 = 3x3 conv down [r][K][3][3] (K = Cin, cs = Cout) whose gradient filter
+  // [K][9*64] at dst_gw has flipped (1) or plain (2: stride-2 layer) taps
+  int conv;
+  int64_t dst_gw;
 };
 // out[M, R] (fp32, row stride ldo) = X[M, K] * S[R, K]^T for R = 16 / 32 (LoRA shadow products), K % 128 == 0
 bool lora_skinny_supported(const void* X, int64_t ldx, const void* S, const float* out, int ldo, int M, int R, int K);

@@ -55,20 +55,34 @@ struct LoraPrepSite {
   int64_t off_down, off_up;  // into the flat fp32 buffers
   int64_t dst_down, dst_up;  // element offsets into the 16-bit shadow buffer
   int r, nseg, K, cs, rows_pad;
+  int conv;                  // see HostLoraPrepSite
+  int64_t dst_gw;
 };
 template <typename T>
 __global__ void lora_prep_kernel(const LoraPrepSite* __restrict__ sites, const float* __restrict__ down,
                                  const float* __restrict__ up, T* __restrict__ shadow) {
   const LoraPrepSite st = sites[blockIdx.y];
   const int rtot = st.r * st.nseg;
-  const int64_t n_down = (int64_t)st.rows_pad * st.K;
+  const int64_t kd = st.conv ? 9 * (int64_t)st.K : st.K;  // row length of the down operand
+  const int64_t n_down = (int64_t)st.rows_pad * kd;
   const int64_t n_up = (int64_t)st.rows_pad * st.nseg * st.cs;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_down + n_up;
+  const int64_t n_gw = st.conv ? (int64_t)st.K * 9 * 64 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_down + n_up + n_gw;
        i += (int64_t)gridDim.x * blockDim.x) {
     if (i < n_down) {
-      const int row = (int)(i / st.K);
-      shadow[st.dst_down + i] = from_f<T>(row < rtot ? down[st.off_down + i] : 0.f);
-    } else {
+      const int row = (int)(i / kd);
+      float v = 0.f;
+      if (row < rtot) {
+        if (st.conv) {  // torch [r][Cin][3][3] -> (ky,kx,ci)-ordered row
+          const int rem = (int)(i - (int64_t)row * kd);
+          const int t = rem / st.K, ci = rem - t * st.K;
+          v = down[st.off_down + ((int64_t)row * st.K + ci) * 9 + t];
+        } else {
+          v = down[st.off_down + i];
+        }
+      }
+      shadow[st.dst_down + i] = from_f<T>(v);
+    } else if (i < n_down + n_up) {
       const int64_t j = i - n_down;
       const int ncols = st.nseg * st.cs;
       const int row = (int)(j / ncols), col = (int)(j - (int64_t)row * ncols);
@@ -78,6 +92,12 @@ __global__ void lora_prep_kernel(const LoraPrepSite* __restrict__ sites, const f
         if (col / st.cs == sgm) v = up[st.off_up + ((int64_t)sgm * st.cs + (col - sgm * st.cs)) * st.r + q];
       }
       shadow[st.dst_up + j] = from_f<T>(v);
+    } else {  // gradient filter of the down conv: gw[ci][tt][q] = down[q][ci][t], tt = 8 - t (flipped) or t (stride 2)
+      const int64_t j = i - n_down - n_up;
+      const int ci = (int)(j / 576), rem = (int)(j - (int64_t)ci * 576);
+      const int tt = rem >> 6, q = rem & 63;
+      const int t = st.conv == 1 ? 8 - tt : tt;
+      shadow[st.dst_gw + j] = from_f<T>(q < st.r ? down[st.off_down + ((int64_t)q * st.K + ci) * 9 + t] : 0.f);
     }
   }
 }
@@ -134,8 +154,24 @@ __global__ __launch_bounds__(256) void lora_wgrad_grouped_partial_kernel(const W
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int m = m0 + u * rpar;
-        const bool ok = m < row1;
-        xv[u].u = ok ? *reinterpret_cast<const u32x4*>(X + (int64_t)m * jb.ldx + col8 * 8) : u32x4{0, 0, 0, 0};
+        bool ok = m < row1;
+        int64_t xrow = m;
+        if (jb.conv_tap >= 0 && ok) {  // output pixel m -> input pixel under this filter tap (3x3, pad 1)
+          const int hw = jb.Hout * jb.Wout;
+          const int img = m / hw, rem = m - img * hw;
+          const int oy = rem / jb.Wout, ox = rem - oy * jb.Wout;
+          int iy = oy * jb.conv_stride + jb.conv_tap / 3 - 1, ix = ox * jb.conv_stride + jb.conv_tap % 3 - 1;
+          const int hl = jb.conv_ups ? 2 * jb.Hin : jb.Hin, wl = jb.conv_ups ? 2 * jb.Win : jb.Win;
+          const bool inside = (unsigned)iy < (unsigned)hl && (unsigned)ix < (unsigned)wl;
+          if (jb.conv_ups) {
+            iy >>= 1;
+            ix >>= 1;
+          }
+          xrow = ((int64_t)img * jb.Hin + iy) * jb.Win + ix;
+          if (!inside) xrow = -1;
+        }
+        const bool ld = ok && xrow >= 0;
+        xv[u].u = ld ? *reinterpret_cast<const u32x4*>(X + xrow * jb.ldx + col8 * 8) : u32x4{0, 0, 0, 0};
         const float rs = (ok && jb.row_scale) ? jb.row_scale[m / jb.rows_per_sample] : 1.f;
 #pragma unroll
         for (int q = 0; q < R; ++q) pv[u][q] = (ok && q < r) ? P[(int64_t)m * jb.ldp + q] * rs : 0.f;

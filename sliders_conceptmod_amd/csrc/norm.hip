@@ -2,8 +2,10 @@
 // HBM-bound: every pass reads/writes each element once with 16-byte lanes; statistics are two-stage and
 // deterministic (per-chunk partials reduced in a fixed order -- no float atomics).
 //
-// GroupNorm forward:  partial(sum, sumsq per (n, chunk, g)) -> finalize (mean, rstd, per-(n,c) affine a,b)
-//                     -> apply  y = silu?(x*a + b)
+// GroupNorm forward:  partial(sum, sumsq per (n, chunk, g)) -> apply: every workgroup first reduces the (<= 64) chunk
+//                     partials of its sample to mean / rstd in LDS (a few KB from L2; a separate "finalize" launch was
+//                     25 us of pure latency, 736 times per step), then y = silu?(x*a + b) for its rows; the workgroup
+//                     of chunk 0 also stores mean / rstd and the per-(n,c) affine a, b for the backward
 // GroupNorm backward: z = x*a+b, dz = dy*silu'(z);  S1 = sum dz*gamma, S2 = sum dz*(z-beta)  per (n,g)
 //                     dx = a*dz + c2*x + c3   with  c2 = -r^2*S2/cnt,  c3 = -r*S1/cnt - c2*mu
 #include "kernels.h"
@@ -11,7 +13,13 @@
 namespace smi {
 namespace {
 
-constexpr int GN_ROWS_PER_CHUNK = 64;  // small chunks: >= 1024 workgroups on the large feature maps
+// rows per chunk: at most 64 chunks per sample (the apply kernels re-reduce the chunk partials), at least 16 rows
+// (the 32x32 maps then still give 64 workgroups per sample).  Depends on HW only, so a sample's arithmetic does not
+// depend on the batch it travels in.
+__host__ __device__ inline int gn_rows_per_chunk(int HW) {
+  const int r = (HW + 63) / 64;
+  return r < 16 ? 16 : (r + 15) / 16 * 16;
+}
 
 struct GnGeom {
   int cols8;  // C / 8
@@ -40,8 +48,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   const int rsub = gg.cols8 >= 256 ? 0 : tid / gg.cols8;
   const int col_base = gg.cols8 >= 256 ? tid : tid - rsub * gg.cols8;
   const bool active = rsub < gg.rpar;
-  const int row0 = chunk * GN_ROWS_PER_CHUNK;
-  const int row1 = min(HW, row0 + GN_ROWS_PER_CHUNK);
+  const int row0 = chunk * gn_rows_per_chunk(HW);
+  const int row1 = min(HW, row0 + gn_rows_per_chunk(HW));
   const float* an = aa + (int64_t)n * C;  // only dereferenced in MODE 1
   const float* bn = bb + (int64_t)n * C;
 
@@ -120,17 +128,22 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   }
 }
 
-// forward finalize: mean/rstd per (n,g) and per-(n,c) affine
-template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(const float* __restrict__ partial,
-                                                              const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                              float* __restrict__ ab, float* __restrict__ mean_rstd,
-                                                              int Nb, int HW, int C, int G, int nchunk, float eps) {
-  extern __shared__ float st[];  // [G][2]
-  const int n = blockIdx.x, tid = threadIdx.x;
+// MODE 0: y = silu?(x*a+b).   MODE 1: dx = a*dz + c2*x + c3 (+ add).
+// Grid (chunk, n) as the partial kernel.  Head: the chunk partials of sample n -> per-group statistics in LDS
+// (8 lanes per group walk the partials, xor tree: fixed order, deterministic), then the rows of this chunk.
+template <typename T, int MODE, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                       const float* __restrict__ partial, float* __restrict__ aa,
+                                                       float* __restrict__ bb, float* __restrict__ mean_rstd,
+                                                       const T* add, T* out, int Nb,
+                                                       int HW, int C, int G, int nchunk, float eps) {
+  extern __shared__ float st[];  // [G][2]: MODE 0 (mean, rstd); MODE 1 (c2, c3)
+  const GnGeom gg = gn_geom(C);
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
   const int cpg = C / G;
-  // 8 lanes per group walk the chunk partials (a serial walk by one lane per group was ~25 us of pure load latency
-  // per launch at 256 chunks); fixed 8-way split + xor tree: deterministic
+  const float cnt = (float)HW * (float)cpg;
   for (int g = tid >> 3; g < G; g += 32) {
     float s = 0.f, sq = 0.f;
     for (int ch = tid & 7; ch < nchunk; ch += 8) {
@@ -144,102 +157,100 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(const float* __res
       sq += __shfl_xor(sq, o);
     }
     if (tid & 7) continue;
-    const float cnt = (float)HW * (float)cpg;
-    const float mean = s / cnt;
-    const float var = fmaxf(sq / cnt - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    st[g * 2] = mean;
-    st[g * 2 + 1] = rstd;
-    mean_rstd[((int64_t)n * G + g) * 2] = mean;
-    mean_rstd[((int64_t)n * G + g) * 2 + 1] = rstd;
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    const float a = st[g * 2 + 1] * to_f(gamma[c]);
-    ab[(int64_t)n * C + c] = a;
-    ab[((int64_t)Nb + n) * C + c] = to_f(beta[c]) - st[g * 2] * a;
-  }
-}
-
-// backward finalize: per-(n,c) coefficients c2, c3 (stored in cd[2][Nb][C])
-template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(const float* __restrict__ partial,
-                                                              const float* __restrict__ mean_rstd,
-                                                              float* __restrict__ cd, int Nb, int HW, int C, int G,
-                                                              int nchunk) {
-  extern __shared__ float st[];  // [G][2] = c2, c3
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int cpg = C / G;
-  for (int g = tid >> 3; g < G; g += 32) {  // 8 lanes per group, as in the forward finalize
-    float s1 = 0.f, s2 = 0.f;
-    for (int ch = tid & 7; ch < nchunk; ch += 8) {
-      const float* p = partial + (((int64_t)n * nchunk + ch) * G + g) * 2;
-      s1 += p[0];
-      s2 += p[1];
-    }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-      s1 += __shfl_xor(s1, o);
-      s2 += __shfl_xor(s2, o);
-    }
-    if (tid & 7) continue;
-    const float cnt = (float)HW * (float)cpg;
-    const float mu = mean_rstd[((int64_t)n * G + g) * 2];
-    const float r = mean_rstd[((int64_t)n * G + g) * 2 + 1];
-    const float c2 = -r * r * s2 / cnt;
-    st[g * 2] = c2;
-    st[g * 2 + 1] = -r * s1 / cnt - c2 * mu;
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    cd[(int64_t)n * C + c] = st[g * 2];
-    cd[((int64_t)Nb + n) * C + c] = st[g * 2 + 1];
-  }
-}
-
-// MODE 0: y = silu?(x*a+b).   MODE 1: dx = a*dz + c2*x + c3
-template <typename T, int MODE, bool SILU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                       const float* __restrict__ aa, const float* __restrict__ bb,
-                                                       const float* __restrict__ cd, const T* add, T* out, int Nb,
-                                                       int HW, int C) {
-  const int cols8 = C / 8;
-  const int64_t total = (int64_t)Nb * HW * cols8;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int col = (int)(i % cols8);
-    const int64_t row = i / cols8;
-    const int n = (int)(row / HW);
-    const float* a = aa + (int64_t)n * C + col * 8;
-    const float* b = bb + (int64_t)n * C + col * 8;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(b), b1 = *reinterpret_cast<const f32x4*>(b + 4);
-    Pack8<T> xv, o;
-    xv.u = *reinterpret_cast<const u32x4*>(x + row * C + col * 8);
     if (MODE == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float z = to_f(xv.e[e]) * (e < 4 ? a0[e & 3] : a1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
-        if (SILU) z = silu_f(z);
-        o.e[e] = from_f<T>(z);
+      const float mean = s / cnt;
+      const float var = fmaxf(sq / cnt - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + eps);
+      st[g * 2] = mean;
+      st[g * 2 + 1] = rstd;
+      if (chunk == 0) {
+        mean_rstd[((int64_t)n * G + g) * 2] = mean;
+        mean_rstd[((int64_t)n * G + g) * 2 + 1] = rstd;
       }
     } else {
-      const float* c2 = cd + (int64_t)n * C + col * 8;
-      const float* c3 = cd + ((int64_t)Nb + n) * C + col * 8;
-      Pack8<T> dv, ad;
-      dv.u = *reinterpret_cast<const u32x4*>(dy + row * C + col * 8);
-      if (add) ad.u = *reinterpret_cast<const u32x4*>(add + row * C + col * 8);
+      const float mu = mean_rstd[((int64_t)n * G + g) * 2];
+      const float r = mean_rstd[((int64_t)n * G + g) * 2 + 1];
+      const float c2 = -r * r * sq / cnt;  // (s, sq) = (S1, S2)
+      st[g * 2] = c2;
+      st[g * 2 + 1] = -r * s / cnt - c2 * mu;
+    }
+  }
+  __syncthreads();
+  const int rsub = gg.cols8 >= 256 ? 0 : tid / gg.cols8;
+  const int col_base = gg.cols8 >= 256 ? tid : tid - rsub * gg.cols8;
+  if (rsub >= gg.rpar) return;
+  const int rpc = gn_rows_per_chunk(HW);
+  const int row0 = chunk * rpc;
+  const int row1 = min(HW, row0 + rpc);
+  float* an = aa + (int64_t)n * C;
+  float* bn = bb + (int64_t)n * C;
+  for (int j = 0; j < gg.ncol; ++j) {
+    const int col = col_base + 256 * j;
+    if (col >= gg.cols8) break;
+    float av[8], bv[8], c2[8], c3[8];
+    if (MODE == 0) {
+      Pack8<T> g8, b8;
+      g8.u = *reinterpret_cast<const u32x4*>(gamma + col * 8);
+      b8.u = *reinterpret_cast<const u32x4*>(beta + col * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float av = (e < 4 ? a0[e & 3] : a1[e & 3]);
-        const float xe = to_f(xv.e[e]);
-        float dz = to_f(dv.e[e]);
-        if (SILU) dz *= dsilu_f(xe * av + (e < 4 ? b0[e & 3] : b1[e & 3]));
-        o.e[e] = from_f<T>(av * dz + c2[e] * xe + c3[e] + (add ? to_f(ad.e[e]) : 0.f));
+        const int g = (col * 8 + e) / cpg;
+        av[e] = st[g * 2 + 1] * to_f(g8.e[e]);
+        bv[e] = to_f(b8.e[e]) - st[g * 2] * av[e];
+      }
+      if (chunk == 0 && rsub == 0) {  // the backward reads the affine back
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          an[col * 8 + e] = av[e];
+          bn[col * 8 + e] = bv[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (col * 8 + e) / cpg;
+        av[e] = an[col * 8 + e];
+        bv[e] = bn[col * 8 + e];
+        c2[e] = st[g * 2];
+        c3[e] = st[g * 2 + 1];
       }
     }
-    *reinterpret_cast<u32x4*>(out + row * C + col * 8) = o.u;
+    for (int r0 = row0 + rsub; r0 < row1; r0 += 4 * gg.rpar) {
+      Pack8<T> xv4[4], dv4[4], ad4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * gg.rpar;
+        const int64_t off = ((int64_t)n * HW + (r < row1 ? r : row0)) * C + col * 8;
+        xv4[u].u = *reinterpret_cast<const u32x4*>(x + off);
+        if (MODE == 1) {
+          dv4[u].u = *reinterpret_cast<const u32x4*>(dy + off);
+          if (add) ad4[u].u = *reinterpret_cast<const u32x4*>(add + off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * gg.rpar;
+        if (r >= row1) continue;
+        Pack8<T> o;
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float z = to_f(xv4[u].e[e]) * av[e] + bv[e];
+            if (SILU) z = silu_f(z);
+            o.e[e] = from_f<T>(z);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xe = to_f(xv4[u].e[e]);
+            float dz = to_f(dv4[u].e[e]);
+            if (SILU) dz *= dsilu_f(xe * av[e] + bv[e]);
+            o.e[e] = from_f<T>(av[e] * dz + c2[e] * xe + c3[e] + (add ? to_f(ad4[u].e[e]) : 0.f));
+          }
+        }
+        *reinterpret_cast<u32x4*>(out + ((int64_t)n * HW + r) * C + col * 8) = o.u;
+      }
+    }
   }
 }
 
@@ -361,23 +372,22 @@ int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float*
   const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
   hipLaunchKernelGGL((gn_partial_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x, nullptr,
                      nullptr, nullptr, ab, ab, partial, Nb, HW, C, G, nchunk);
-  hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(Nb), dim3(256), G * 2 * sizeof(float), st, partial,
-                     (const T*)gamma, (const T*)beta, ab, mean_rstd, Nb, HW, C, G, nchunk, eps);
-  const int grid = ew_grid((int64_t)Nb * HW * (C / 8));
+  const size_t sa = (size_t)G * 2 * sizeof(float);
   if (silu)
-    hipLaunchKernelGGL((gn_apply_kernel<T, 0, true>), dim3(grid), dim3(256), 0, st, (const T*)x, nullptr, ab,
-                       ab + (size_t)Nb * C, nullptr, nullptr, (T*)y, Nb, HW, C);
+    hipLaunchKernelGGL((gn_apply_kernel<T, 0, true>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, nullptr,
+                       (const T*)gamma, (const T*)beta, partial, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, Nb, HW, C, G, nchunk, eps);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<T, 0, false>), dim3(grid), dim3(256), 0, st, (const T*)x, nullptr, ab,
-                       ab + (size_t)Nb * C, nullptr, nullptr, (T*)y, Nb, HW, C);
+    hipLaunchKernelGGL((gn_apply_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, nullptr,
+                       (const T*)gamma, (const T*)beta, partial, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, Nb, HW, C, G, nchunk, eps);
   SMI_HIP(hipGetLastError());
   return 0;
 }
 
+// aa / bb: the forward's per-(n,c) affine of the Nb samples being differentiated ([Nb][C] each)
 template <typename T>
 int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta, const float* aa, const float* bb,
-             const float* mean_rstd, const void* add, void* dx, float* partial, float* cd, int Nb, int HW, int C,
-             int G, int silu, hipStream_t st) {
+             const float* mean_rstd, const void* add, void* dx, float* partial, int Nb, int HW, int C, int G, int silu,
+             hipStream_t st) {
   const int nchunk = gn_num_chunks(HW);
   const GnGeom gg = gn_geom(C);
   const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
@@ -387,22 +397,23 @@ int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta,
   else
     hipLaunchKernelGGL((gn_partial_kernel<T, 1, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x,
                        (const T*)dy, (const T*)gamma, (const T*)beta, aa, bb, partial, Nb, HW, C, G, nchunk);
-  hipLaunchKernelGGL(gn_finalize_bwd_kernel<T>, dim3(Nb), dim3(256), G * 2 * sizeof(float), st, partial, mean_rstd, cd,
-                     Nb, HW, C, G, nchunk);
-  const int grid = ew_grid((int64_t)Nb * HW * (C / 8));
+  const size_t sa = (size_t)G * 2 * sizeof(float);
+  float* abp = const_cast<float*>(aa);
+  float* bbp = const_cast<float*>(bb);
+  float* mrp = const_cast<float*>(mean_rstd);
   if (silu)
-    hipLaunchKernelGGL((gn_apply_kernel<T, 1, true>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, aa, bb, cd,
-                       (const T*)add, (T*)dx, Nb, HW, C);
+    hipLaunchKernelGGL((gn_apply_kernel<T, 1, true>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, (const T*)dy,
+                       (const T*)gamma, (const T*)beta, partial, abp, bbp, mrp, (const T*)add, (T*)dx, Nb, HW, C, G, nchunk, 0.f);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<T, 1, false>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, aa, bb,
-                       cd, (const T*)add, (T*)dx, Nb, HW, C);
+    hipLaunchKernelGGL((gn_apply_kernel<T, 1, false>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, (const T*)dy,
+                       (const T*)gamma, (const T*)beta, partial, abp, bbp, mrp, (const T*)add, (T*)dx, Nb, HW, C, G, nchunk, 0.f);
   SMI_HIP(hipGetLastError());
   return 0;
 }
 
 }  // namespace
 
-int gn_num_chunks(int HW) { return (HW + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK; }
+int gn_num_chunks(int HW) { return (HW + gn_rows_per_chunk(HW) - 1) / gn_rows_per_chunk(HW); }
 
 int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* ab,
                          float* mean_rstd, float* partial, int Nb, int HW, int C, int G, float eps, int silu,
@@ -413,15 +424,14 @@ int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void
                          : gn_fwd_t<bf16>(x, gamma, beta, y, ab, mean_rstd, partial, Nb, HW, C, G, eps, silu, stream);
 }
 
-// `partial` must hold Nb*nchunk*G*2 floats followed by 2*Nb*C floats (the c2/c3 coefficient arrays)
+// `partial` must hold Nb*nchunk*G*2 floats.  `a`, `b`: the forward's affine of these Nb samples ([Nb][C] each).
 int launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const void* beta,
                          const float* a, const float* b, const float* mean_rstd, const void* add, void* dx,
                          float* partial, int Nb, int HW, int C, int G, int silu, hipStream_t stream) {
   SMI_CHECK(C % 8 == 0 && C % G == 0, "groupnorm bwd: C=%d G=%d", C, G);
-  float* cd = partial + (size_t)Nb * gn_num_chunks(HW) * G * 2;
   return dtype == DT_F16
-             ? gn_bwd_t<f16>(x, dy, gamma, beta, a, b, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream)
-             : gn_bwd_t<bf16>(x, dy, gamma, beta, a, b, mean_rstd, add, dx, partial, cd, Nb, HW, C, G, silu, stream);
+             ? gn_bwd_t<f16>(x, dy, gamma, beta, a, b, mean_rstd, add, dx, partial, Nb, HW, C, G, silu, stream)
+             : gn_bwd_t<bf16>(x, dy, gamma, beta, a, b, mean_rstd, add, dx, partial, Nb, HW, C, G, silu, stream);
 }
 
 int launch_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean_rstd,

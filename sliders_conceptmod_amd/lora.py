@@ -36,17 +36,18 @@ TRAINING_METHODS = Literal["noxattn", "innoxattn", "selfattn", "xattn", "full", 
 
 
 class _WeightView:
-    """Stand-in for the nn.Linear the reference keeps in `lora_down` / `lora_up`: `.weight` is a live view."""
+    """Stand-in for the nn.Linear / nn.Conv2d the reference keeps in `lora_down` / `lora_up`: `.weight` is a live view
+    ([out, in] for Linear, [out, in, kh, kw] for Conv2d -- the shapes the reference's state_dict holds)."""
 
     def __init__(self, owner: "LoRANetwork", which: str, offset: int, shape):
         self._owner, self._which, self._offset, self._shape = owner, which, offset, tuple(shape)
         self.in_features, self.out_features = shape[1], shape[0]
+        self._numel = math.prod(self._shape)
 
     @property
     def weight(self) -> torch.Tensor:
         flat = self._owner.flat_down if self._which == "down" else self._owner.flat_up
-        n = self._shape[0] * self._shape[1]
-        return flat[self._offset:self._offset + n].view(self._shape)
+        return flat[self._offset:self._offset + self._numel].view(self._shape)
 
     @property
     def grad(self) -> Optional[torch.Tensor]:
@@ -54,35 +55,50 @@ class _WeightView:
         if g is None:
             return None
         base = self._offset + (0 if self._which == "down" else self._owner._n_down)
-        return g[base:base + self._shape[0] * self._shape[1]].view(self._shape)
+        return g[base:base + self._numel].view(self._shape)
+
+
+def lora_shapes(org_module: nn.Module, lora_dim: int):
+    """(rank actually used, lora_down.weight shape, lora_up.weight shape) -- lora.py:94-114: Linear [r, in] / [out, r];
+    Conv2d: k x k down with the layer's stride / padding, 1 x 1 up, rank clamped to min(rank, in, out)."""
+    if isinstance(org_module, nn.Linear):
+        return lora_dim, (lora_dim, org_module.in_features), (org_module.out_features, lora_dim)
+    if isinstance(org_module, nn.Conv2d):
+        r = min(lora_dim, org_module.in_channels, org_module.out_channels)
+        kh, kw = org_module.kernel_size
+        return r, (r, org_module.in_channels, kh, kw), (org_module.out_channels, r, 1, 1)
+    raise NotImplementedError(f"LoRA on {org_module.__class__.__name__}")
 
 
 class LoRAModule:
-    """One adapted Linear: y = W x + up(down(x)) * multiplier * (alpha / rank)   (lora.py:134-138)."""
+    """One adapted Linear or Conv2d: y = org(x) + up(down(x)) * multiplier * (alpha / rank)   (lora.py:76-138)."""
 
     def __init__(self, owner, lora_name, target_path, org_module, multiplier, lora_dim, alpha, off_down, off_up):
-        if not isinstance(org_module, nn.Linear):
-            raise NotImplementedError(
-                f"{lora_name}: only Linear (attention projection) adaptors are built in this tier; conv/c3lier "
-                f"adaptors (lora.py:100-114) are listed as a 'next' row in DESIGN.md")
         self.lora_name = lora_name
         self.target_path = target_path
-        self.lora_dim = lora_dim
-        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        self.lora_dim, down_shape, up_shape = lora_shapes(org_module, lora_dim)
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha  # sic: the UNCLAMPED rank (lora.py:118)
         self.scale = alpha / self.lora_dim
         self.alpha = torch.tensor(alpha)
         self.multiplier = multiplier
-        self.in_dim, self.out_dim = org_module.in_features, org_module.out_features
+        self.is_conv = isinstance(org_module, nn.Conv2d)
+        self.in_dim, self.out_dim = down_shape[1], up_shape[0]
         self.off_down, self.off_up = off_down, off_up
-        self.lora_down = _WeightView(owner, "down", off_down, (lora_dim, self.in_dim))
-        self.lora_up = _WeightView(owner, "up", off_up, (self.out_dim, lora_dim))
+        self.lora_down = _WeightView(owner, "down", off_down, down_shape)
+        self.lora_up = _WeightView(owner, "up", off_up, up_shape)
 
     def parameters(self):
         return [self.lora_down.weight, self.lora_up.weight]
 
 
-def select_targets(root_module: nn.Module, train_method: str, target_replace_modules, prefix: str, delimiter: str):
-    """The name / class-name walk of lora.py:194-251, returning (lora_name, dotted path, child module)."""
+def select_targets(root_module: nn.Module, train_method: str, target_replace_modules, prefix: str, delimiter: str,
+                   with_duplicates: bool = False):
+    """The name / class-name walk of lora.py:194-251, returning (lora_name, dotted path, child module).
+
+    With the conv classes in `target_replace_modules` (c3lier) a resnet conv is reached twice -- through its
+    DownBlock2D / UpBlock2D and again through its ResnetBlock2D; the reference BUILDS a LoRAModule both times (drawing
+    its init from the global RNG) and keeps the first (lora.py:243-249).  `with_duplicates` returns those second visits
+    too, as (lora_name, path, child, True), so the init can consume the RNG identically."""
     out, names = [], []
     for name, module in root_module.named_modules():
         if train_method in ("noxattn", "noxattn-hspace", "noxattn-hspace-last"):
@@ -117,7 +133,10 @@ def select_targets(root_module: nn.Module, train_method: str, target_replace_mod
                     lora_name = (prefix + "." + name + "." + child_name).replace(".", delimiter)
                     if lora_name not in names:
                         names.append(lora_name)
-                        out.append((lora_name, name + "." + child_name, child_module))
+                        out.append((lora_name, name + "." + child_name, child_module) +
+                                   ((False,) if with_duplicates else ()))
+                    elif with_duplicates:
+                        out.append((lora_name, name + "." + child_name, child_module, True))
     return out
 
 
@@ -130,29 +149,37 @@ class LoRANetwork(nn.Module):
         self.multiplier = multiplier
         self.lora_dim = rank
         self.alpha = alpha
-        targets = select_targets(unet, train_method, target_replace, prefix, delimiter)
-        n_down = sum(rank * c.in_features for _, _, c in targets if isinstance(c, nn.Linear))
-        n_up = sum(rank * c.out_features for _, _, c in targets if isinstance(c, nn.Linear))
+        visits = select_targets(unet, train_method, target_replace, prefix, delimiter, with_duplicates=True)
+        targets = [v[:3] for v in visits if not v[3]]
+        n_down = sum(math.prod(lora_shapes(c, rank)[1]) for _, _, c in targets)
+        n_up = sum(math.prod(lora_shapes(c, rank)[2]) for _, _, c in targets)
         self._n_down, self._n_up = n_down, n_up
         self.flat = nn.Parameter(torch.zeros(max(n_down + n_up, 1), dtype=torch.float32))
         self.unet_loras: List[LoRAModule] = []
         od = ou = 0
+        by_name = {}
         for lora_name, path, child in targets:
             m = LoRAModule(self, lora_name, path, child, multiplier, rank, alpha, od, ou)
             self.unet_loras.append(m)
-            od += rank * m.in_dim
-            ou += rank * m.out_dim
+            by_name[lora_name] = m
+            od += m.lora_down._numel
+            ou += m.lora_up._numel
         lora_names = set()
         for lora in self.unet_loras:
             assert lora.lora_name not in lora_names, f"duplicated lora name: {lora.lora_name}. {lora_names}"
             lora_names.add(lora.lora_name)
         with torch.no_grad():  # lora.py:123-124: kaiming_uniform_(down, a=1); zeros_(up) -- same RNG draw order
-            for lora in self.unet_loras:
-                # the reference builds nn.Linear(in, r) and nn.Linear(r, out) first (lora.py:97-98); their default
-                # inits consume the global RNG, so draw-and-discard the same amounts to stay seed-compatible
-                torch.empty(lora.lora_dim, lora.in_dim).uniform_()
-                torch.empty(lora.out_dim, lora.lora_dim).uniform_()
-                nn.init.kaiming_uniform_(lora.lora_down.weight, a=1)
+            for lora_name, _path, child, dup in visits:
+                # the reference builds nn.Linear / nn.Conv2d layers first (lora.py:97-98, 109-112); their default inits
+                # consume the global RNG, so draw-and-discard the same amounts to stay seed-compatible -- also for the
+                # modules it builds and then drops as duplicates (lora.py:243-249)
+                _r, dshape, ushape = lora_shapes(child, rank)
+                torch.empty(dshape).uniform_()
+                torch.empty(ushape).uniform_()
+                if dup:
+                    nn.init.kaiming_uniform_(torch.empty(dshape), a=1)
+                else:
+                    nn.init.kaiming_uniform_(by_name[lora_name].lora_down.weight, a=1)
         # "apply_to": register with the engine-backed UNet instead of patching module forwards (lora.py:129-132)
         unet.__dict__["_lora_network"] = self  # plain attribute: must not become a registered child module
 
@@ -166,6 +193,7 @@ class LoRANetwork(nn.Module):
 
     # ---- engine side ---------------------------------------------------------------------------------------------
     def engine_sites(self):
+        # the engine tells Linear from Conv2d targets by the module path (conv1 / conv2 / *samplers.0.conv)
         return [{"target": l.target_path, "off_down": l.off_down, "off_up": l.off_up, "rank": l.lora_dim,
                  "scale": float(l.scale)} for l in self.unet_loras]
 

@@ -5,8 +5,7 @@ reference script (conceptmod/textsliders/train_lora.py:32-419), on the HIP engin
            --attributes "male, female"
 
 Differences, all recorded in DESIGN.md: the reference's stale 6-argument PromptEmbedsPair / `unconditional_latents`
-call works (prompt_util.py here accepts both forms); `c3lier` falls back to attention-only adaptors with a warning
-(conv adaptors are a 'next' row); `--device cpu` is rejected (no CPU path); under torch.distributed.run the batch is
+call works (prompt_util.py here accepts both forms); `--device cpu` is rejected (no CPU path); under torch.distributed.run the batch is
 sharded over ranks and the LoRA gradient is all-reduced."""
 import argparse
 import ast
@@ -18,7 +17,7 @@ from tqdm import tqdm
 
 from . import config_util, model_util, parallel, prompt_util, train_util
 from .config_util import RootConfig
-from .lora import DEFAULT_TARGET_REPLACE, LoRANetwork
+from .lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV, LoRANetwork
 from .prompt_util import PromptEmbedsCache, PromptEmbedsPair, PromptSettings
 
 
@@ -33,9 +32,11 @@ def encode(text_encoder, tokenizer, prompt, device, dtype):
 def train(config: RootConfig, prompts: list, device, models=None, on_step_complete=None, save_file=True):
     metadata = {"prompts": ",".join([p.model_dump_json() for p in prompts]), "config": config.model_dump_json()}
     save_path = Path(config.save.path)
+    # train_lora.py:44-46: `modules = DEFAULT_TARGET_REPLACE; modules += UNET_TARGET_REPLACE_MODULE_CONV` mutates the list
+    # that LoRANetwork's default argument is bound to, which is how c3lier reaches the network there; here it is passed
+    modules = list(DEFAULT_TARGET_REPLACE)
     if config.network.type == "c3lier":
-        print("[sliders_conceptmod_amd] network.type c3lier: conv/time-embedding adaptors are not built in this tier; "
-              "training attention-only (lierla) adaptors", file=sys.stderr)
+        modules += UNET_TARGET_REPLACE_MODULE_CONV
     weight_dtype = config_util.parse_precision(config.train.precision)
     save_weight_dtype = config_util.parse_precision(config.train.precision)  # sic: train.precision (train_lora.py:55)
     if weight_dtype == torch.float32:
@@ -52,7 +53,8 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
     unet.requires_grad_(False)
     unet.eval()
     network = LoRANetwork(unet, rank=config.network.rank, multiplier=1.0, alpha=config.network.alpha,
-                          train_method=config.network.training_method).to(device, dtype=weight_dtype)
+                          train_method=config.network.training_method, target_replace=modules).to(device,
+                                                                                                   dtype=weight_dtype)
     parallel.broadcast_(network.flat.data)
     optimizer_module = train_util.get_optimizer(config.train.optimizer)
     optimizer_kwargs = {}

@@ -21,7 +21,7 @@ import torch
 from tqdm import tqdm
 
 from . import config_util, model_util, parallel, prompt_util, train_util
-from .lora import LoRANetwork
+from .lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV, LoRANetwork
 from .train_lora_xl import encode_xl
 
 
@@ -65,8 +65,12 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     unet.to(device, dtype=weight_dtype)
     unet.requires_grad_(False)
     unet.eval()
+    modules = list(DEFAULT_TARGET_REPLACE)  # I/train_lora-scale-xl.py:57-59: c3lier adds the conv classes
+    if config.network.type == "c3lier":
+        modules += UNET_TARGET_REPLACE_MODULE_CONV
     network = LoRANetwork(unet, rank=rank, multiplier=1.0, alpha=config.network.alpha,
-                          train_method=config.network.training_method).to(device, dtype=weight_dtype)
+                          train_method=config.network.training_method, target_replace=modules).to(device,
+                                                                                                   dtype=weight_dtype)
     parallel.broadcast_(network.flat.data)
     optimizer = train_util.get_optimizer(config.train.optimizer)(network.prepare_optimizer_params(),
                                                                  lr=config.train.lr)

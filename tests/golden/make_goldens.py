@@ -357,6 +357,42 @@ def main():
         sched = S.create_noise_scheduler_ref(sched_name)
         run_trajectory(model, cfg, sched, xl, f"traj_smooth/{model}", {"eps": SMOOTH_EPS[model]}, full_sd=True)
 
+    # ------------------------------------------------------------------ (8) c3lier: conv / time-embedding adaptors
+    # The shipped SD-1.x config trains `type: c3lier` (data/config.yaml:7): train_lora.py:44-46 appends the conv classes to
+    # the target list.  Pinned here: selection incl. the duplicate-name pass (DownBlock2D / UpBlock2D reach the same
+    # convs as ResnetBlock2D, lora.py:243-249), shapes with the rank clamp, and the RNG-dependent init of modules that
+    # come AFTER such duplicates (the reference builds -- and seeds -- the dropped duplicates too).
+    c3 = list(ref_lora.UNET_TARGET_REPLACE_MODULE_TRANSFORMER) + [
+        "ResnetBlock2D", "Downsample2D", "Upsample2D", "DownBlock2D", "UpBlock2D"]  # lora.py:19-26
+    sel3 = {}
+    for model, cfg in [("sd1x", U.sd1x_config()), ("sdxl", U.sdxl_config()),
+                       ("tiny_sd1x", U.tiny_sd1x_config()), ("tiny_sdxl", U.tiny_sdxl_config())]:
+        for method in ["noxattn", "full"]:
+            with torch.device("meta"):
+                unet = U.UNet2DConditionModel(cfg)
+            net = ref_lora.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, target_replace=c3, train_method=method)
+            names = [l.lora_name for l in net.unet_loras]
+            shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+            sel3[f"{model}/{method}"] = {
+                "n_modules": len(names), "n_params": sum(p.numel() for p in net.parameters()),
+                "names_sha": __import__("hashlib").sha256("\n".join(names).encode()).hexdigest(),
+                "shapes_sha": __import__("hashlib").sha256(json.dumps(shapes, sort_keys=True).encode()).hexdigest(),
+            }
+            if model.startswith("tiny"):
+                sel3[f"{model}/{method}"]["names"] = names
+    manifest["selection_c3lier"] = sel3
+    for model, cfg in [("tiny_sd1x", U.tiny_sd1x_config()), ("tiny_sdxl", U.tiny_sdxl_config())]:
+        unet = U.init_synthetic_(U.UNet2DConditionModel(cfg), seed=0)
+        torch.manual_seed(1)
+        net = ref_lora.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, target_replace=c3, train_method="noxattn")
+        picks = [net.unet_loras[0], net.unet_loras[len(net.unet_loras) // 2], net.unet_loras[-1]]
+        picks += [l for l in net.unet_loras if "conv_shortcut" in l.lora_name][:1]
+        picks += [l for l in net.unet_loras if "time_emb_proj" in l.lora_name][-1:]
+        picks += [l for l in net.unet_loras if l.lora_name.endswith("samplers_0_conv")][-1:]
+        for l in picks:
+            tensors[f"c3lier_init/{model}/{l.lora_name}.lora_down.weight"] = l.lora_down.weight.detach().clone()
+        manifest[f"c3lier_init/{model}"] = {"seed": 1, "after_init_randint": int(torch.randint(0, 2 ** 31 - 1, (1,)))}
+
     save_file(tensors, os.path.join(OUT, "harness_goldens.safetensors"))
     with open(os.path.join(OUT, "harness_goldens.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

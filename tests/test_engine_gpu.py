@@ -26,7 +26,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def build_pair(model, dtype, method="noxattn", rank=4, lora_seed=2, ocfg=None):
+def build_pair(model, dtype, method="noxattn", rank=4, lora_seed=2, ocfg=None, c3lier=False):
     import sliders_conceptmod_amd.lora as L
     import sliders_conceptmod_amd.unet as PU
     ocfg = ocfg or CFGS[model]()
@@ -35,9 +35,15 @@ def build_pair(model, dtype, method="noxattn", rank=4, lora_seed=2, ocfg=None):
     pu.load_state_dict(ou.state_dict())
     pu = pu.to("cuda", dtype).requires_grad_(False).eval()
     torch.manual_seed(1)
-    onet = R.LoRANetworkRef(ou, rank, 1.0, 1.0, method)
-    torch.manual_seed(1)
-    pnet = L.LoRANetwork(pu, rank=rank, multiplier=1.0, alpha=1.0, train_method=method)
+    if c3lier:
+        onet = R.LoRANetworkRef(ou, rank, 1.0, 1.0, method, target_replace=R.C3LIER_TARGET_REPLACE)
+        torch.manual_seed(1)
+        pnet = L.LoRANetwork(pu, rank=rank, multiplier=1.0, alpha=1.0, train_method=method,
+                             target_replace=L.UNET_TARGET_REPLACE_MODULE_TRANSFORMER + L.UNET_TARGET_REPLACE_MODULE_CONV)
+    else:
+        onet = R.LoRANetworkRef(ou, rank, 1.0, 1.0, method)
+        torch.manual_seed(1)
+        pnet = L.LoRANetwork(pu, rank=rank, multiplier=1.0, alpha=1.0, train_method=method)
     g = torch.Generator().manual_seed(lora_seed)
     with torch.no_grad():
         for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
@@ -303,3 +309,54 @@ def test_backward_through_a_superseded_forward_fails_loudly():
         pu(x2, 499.0, encoder_hidden_states=ctx.cuda())  # another shape: replan drops the tape
     with pytest.raises(SmiError, match="saved activations are gone"):
         c.sum().backward()
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+@pytest.mark.parametrize("method", ["noxattn", "full"])
+def test_c3lier_forward_and_gradients_match_oracle(model, method):
+    """`network.type: c3lier` (the shipped SD-1.x config, T/data/config.yaml:7): adaptors on the resnet convs (3x3 down
+    conv -> 1x1 up, T/lora.py:100-114), time_emb_proj, conv_shortcut and the sampler convs (stride 2 / nearest-2x) next
+    to the attention ones; forward and every LoRA gradient against the oracle's autograd."""
+    dtype = torch.float16
+    ocfg, ou, onet, pu, pnet = build_pair(model, dtype, method=method, c3lier=True)
+    kinds = {"conv1": 0, "conv2": 0, "time_emb_proj": 0, "conv_shortcut": 0, "samplers_0_conv": 0, "attn1": 0}
+    if method == "full":
+        kinds["attn2"] = 0
+    for l in pnet.unet_loras:
+        for k in kinds:
+            kinds[k] += k in l.lora_name
+    assert all(v > 0 for v in kinds.values()), kinds
+    x, ctx, add = inputs(ocfg, 2, 16)
+    g = torch.Generator().manual_seed(9)
+    gy = torch.randn(2, 4, 16, 16, generator=g) * 1e-4
+    with torch.no_grad():
+        onet.__exit__(None, None, None)
+        off = ou(x, 499.0, ctx, add).sample
+    with onet:
+        ref = ou(x, 499.0, ctx, add).sample
+    (ref * gy).sum().backward()
+    with pnet:
+        got = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+    (got * gy.cuda()).sum().backward()
+    e = rel(got, ref)
+    assert rel(ref, off) > 1e-2  # the conv adaptors move the output a lot more than the attention-only ones
+    assert e < LOOSE[dtype], e
+    by_kind = {}
+    tot_num = tot_den = 0.0
+    for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+        assert lo.lora_name == lp.lora_name
+        kind = next(k for k in kinds if k in lo.lora_name)
+        for a, b in ((lp.lora_down.grad, lo.lora_down.weight.grad), (lp.lora_up.grad, lo.lora_up.weight.grad)):
+            assert a.shape == b.shape and b.abs().max() > 0, lo.lora_name
+            n_, d_ = (a.cpu() - b).norm().item() ** 2, b.norm().item() ** 2
+            acc = by_kind.setdefault(kind, [0.0, 0.0])
+            acc[0] += n_
+            acc[1] += d_
+            tot_num += n_
+            tot_den += d_
+    errs = {k: (v[0] / v[1]) ** 0.5 for k, v in by_kind.items()}
+    glob = (tot_num / tot_den) ** 0.5
+    print(f"{model} {method} c3lier: eps {e:.2e}, LoRA-grad global {glob:.2e}, by kind " +
+          ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert glob < 8e-3, glob
+    assert all(v < 2.5e-2 for v in errs.values()), errs

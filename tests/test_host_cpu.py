@@ -165,3 +165,44 @@ def test_engine_rejects_unsupported_lora_target(libpath):
     with pytest.raises(_native.SmiError, match="not an attention projection"):
         _native.workspace_bytes(cc, [{"target": "down_blocks.0.resnets.0.time_emb_proj", "off_down": 0, "off_up": 0,
                                       "rank": 4, "scale": 0.25}], 2, 16, 16, 77)
+
+
+# ---- c3lier (reference: T/lora.py:19-26,100-114,243-249; T/train_lora.py:44-46; T/data/config.yaml:7) -------------
+C3 = L.UNET_TARGET_REPLACE_MODULE_TRANSFORMER + L.UNET_TARGET_REPLACE_MODULE_CONV
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+@pytest.mark.parametrize("method", ["noxattn", "full"])
+def test_c3lier_names_and_shapes_match_reference(goldens, model, method):
+    _, man = goldens
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(pcfg(CFGS[model]()))
+    net = L.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, train_method=method, target_replace=C3)
+    g = man["selection_c3lier"][f"{model}/{method}"]
+    names = [l.lora_name for l in net.unet_loras]
+    assert len(names) == g["n_modules"]
+    assert hashlib.sha256("\n".join(names).encode()).hexdigest() == g["names_sha"]
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert hashlib.sha256(json.dumps(shapes, sort_keys=True).encode()).hexdigest() == g["shapes_sha"]
+    assert sum(p.numel() for p in net.parameters()) == g["n_params"]
+
+
+@pytest.mark.parametrize("model", ["tiny_sd1x", "tiny_sdxl"])
+def test_c3lier_init_is_seed_compatible_with_reference(goldens, model):
+    t, man = goldens
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(pcfg(CFGS[model]()))
+    torch.manual_seed(man[f"c3lier_init/{model}"]["seed"])
+    net = L.LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn", target_replace=C3)
+    assert int(torch.randint(0, 2 ** 31 - 1, (1,))) == man[f"c3lier_init/{model}"]["after_init_randint"]
+    sd = net.state_dict()
+    keys = [k for k in t if k.startswith(f"c3lier_init/{model}/")]
+    assert len(keys) >= 5
+    for k in keys:
+        torch.testing.assert_close(sd[k.split("/")[2]], t[k], rtol=0, atol=0)
+
+
+def test_conv_lora_rank_is_clamped_and_scale_uses_it():
+    conv = torch.nn.Conv2d(2, 8, 3, 1, 1)
+    r, dshape, ushape = L.lora_shapes(conv, 4)
+    assert (r, dshape, ushape) == (2, (2, 2, 3, 3), (8, 2, 1, 1))  # min(rank, in, out): T/lora.py:104

@@ -204,3 +204,36 @@ def test_training_trajectory_matches_reference(goldens, model):
         assert float(sd[k].float().norm()) == pytest.approx(nrm, rel=2e-3, abs=1e-6), k
     for k in [k for k in t if k.startswith(f"traj/{model}/sd/")]:
         torch.testing.assert_close(sd[k.split("/sd/")[1]], t[k], rtol=2e-3, atol=2e-5)
+
+
+# ---- c3lier (conv / time-embedding adaptors; T/lora.py:19-26,100-114,243-249; T/train_lora.py:44-46) -----------------
+@pytest.mark.parametrize("model", list(CFGS))
+@pytest.mark.parametrize("method", ["noxattn", "full"])
+def test_c3lier_selection_matches_reference(goldens, model, method):
+    _, man = goldens
+    with torch.device("meta"):
+        unet = U.UNet2DConditionModel(CFGS[model]())
+        net = R.LoRANetworkRef(unet, 4, 1.0, 1.0, method, target_replace=R.C3LIER_TARGET_REPLACE)
+    names = [l.lora_name for l in net.unet_loras]
+    g = man["selection_c3lier"][f"{model}/{method}"]
+    assert len(names) == g["n_modules"]
+    assert hashlib.sha256("\n".join(names).encode()).hexdigest() == g["names_sha"]
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert hashlib.sha256(json.dumps(shapes, sort_keys=True).encode()).hexdigest() == g["shapes_sha"]
+    assert sum(p.numel() for p in net.parameters()) == g["n_params"]
+
+
+@pytest.mark.parametrize("model", ["tiny_sd1x", "tiny_sdxl"])
+def test_c3lier_init_consumes_the_rng_like_the_reference(goldens, model):
+    """Modules after a duplicate visit only get the reference's init if the dropped duplicates are built too."""
+    t, man = goldens
+    unet = U.init_synthetic_(U.UNet2DConditionModel(CFGS[model]()), seed=0)
+    torch.manual_seed(man[f"c3lier_init/{model}"]["seed"])
+    net = R.LoRANetworkRef(unet, 4, 1.0, 1.0, "noxattn", target_replace=R.C3LIER_TARGET_REPLACE)
+    assert int(torch.randint(0, 2 ** 31 - 1, (1,))) == man[f"c3lier_init/{model}"]["after_init_randint"]
+    by_name = {l.lora_name: l for l in net.unet_loras}
+    keys = [k for k in t if k.startswith(f"c3lier_init/{model}/")]
+    assert len(keys) >= 5
+    for k in keys:
+        name = k.split("/")[2].rsplit(".lora_down.weight", 1)[0]
+        torch.testing.assert_close(by_name[name].lora_down.weight.detach(), t[k], rtol=0, atol=0)
