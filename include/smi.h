@@ -71,6 +71,18 @@ typedef struct smi_lora_site {
   float scale;
 } smi_lora_site;
 
+/* Architecture of the diffusers AutoencoderKL ENCODER half (image sliders encode their image pairs with it every step:
+ * trainscripts/imagesliders/train_util.py:213-222). */
+typedef struct smi_vae_config {
+  int dtype;
+  int in_channels;      /* 3 */
+  int latent_channels;  /* 4: the encoder emits 2 x latent_channels moments (mean | logvar) */
+  int n_levels;         /* len(block_out_channels) */
+  int block_out_channels[SMI_MAX_LEVELS]; /* (128, 256, 512, 512) */
+  int layers_per_block; /* 2 */
+  int norm_num_groups;  /* 32 */
+} smi_vae_config;
+
 typedef struct smi_engine smi_engine;
 
 const char* smi_last_error(void);
@@ -107,6 +119,20 @@ int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ct
  * forward whose tape is live (0: none; each save_for_backward forward gets a new number -- callers keep it next to the
  * output they will differentiate and compare before smi_unet_backward), out[3] = bytes of the packed-weight region. */
 int smi_engine_stats(const smi_engine* e, int64_t out[4]);
+
+/* ---- AutoencoderKL encoder (image sliders) ------------------------------------------------------------------------
+ * moments = quant_conv(encoder(image)): replaces `vae.encode(image)` up to the posterior's parameters
+ * (trainscripts/imagesliders/train_util.py:218: `vae.encode(image).latent_dist`); the caller draws the sample
+ * (mean + exp(0.5 clamp(logvar, -30, 20)) eps) and multiplies by scaling_factor (:219-220).
+ *   weights: diffusers AutoencoderKL state_dict entries `encoder.*` and `quant_conv.*`, dtype T
+ *   image   f32 [n, 3, h, w], already preprocessed to [-1, 1] (VaeImageProcessor.preprocess)
+ *   moments f32 [n, 2 * latent_channels, h / 8, w / 8]   (mean | logvar, unclamped)
+ * h, w are the IMAGE size (multiples of 8 x 2^(n_levels-1)/... : each level but the last halves it).  Same ownership
+ * rules as the UNet engine; smi_destroy frees it. */
+int smi_vae_workspace_bytes(const smi_vae_config* cfg, int batch, int h, int w, size_t* bytes);
+int smi_vae_create(const smi_vae_config* cfg, const smi_weight* weights, int n_weights, int batch, int h, int w,
+                   void* workspace, size_t workspace_bytes, void* stream, smi_engine** out);
+int smi_vae_encode(smi_engine* e, int n, const float* image, float* moments_out);
 
 /* eps = unet(sample, t, ctx[, text_embeds, time_ids]).sample           (train_util.py:290-294, 471-476)
  *   sample      f32 [n, 4, h, w]  (NCHW, already scale_model_input-ed)

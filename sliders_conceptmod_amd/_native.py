@@ -31,6 +31,12 @@ class UNetConfigC(C.Structure):
     ]
 
 
+class VaeConfigC(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("in_channels", C.c_int), ("latent_channels", C.c_int), ("n_levels", C.c_int),
+                ("block_out_channels", C.c_int * SMI_MAX_LEVELS), ("layers_per_block", C.c_int),
+                ("norm_num_groups", C.c_int)]
+
+
 class WeightC(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
 
@@ -57,6 +63,10 @@ _SIGS = {
                                   C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "smi_replan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "smi_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "smi_vae_workspace_bytes": (C.c_int, [C.POINTER(VaeConfigC), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "smi_vae_create": (C.c_int, [C.POINTER(VaeConfigC), C.POINTER(WeightC), C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "smi_vae_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "smi_unet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "smi_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -278,6 +288,65 @@ class Engine:
         check(lib().smi_profile_read(self.handle, ms, fl, by, la), "smi_profile_read")
         return {k: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": la[i]}
                 for i, k in enumerate(self.PROF_CLASSES)}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().smi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _weight_table(state: dict, dtype, device):
+    warr = (WeightC * len(state))()
+    keep = []
+    for i, (k, v) in enumerate(state.items()):
+        if v.dtype != dtype or not v.is_contiguous() or v.device != device:
+            raise SmiError(f"weight {k}: expected contiguous {dtype} on {device}")
+        nb = k.encode()
+        keep.append((nb, v))
+        warr[i].name = nb
+        warr[i].data = v.data_ptr()
+        warr[i].ndim = v.ndim
+        for d in range(v.ndim):
+            warr[i].shape[d] = v.shape[d]
+    return warr, keep
+
+
+class VaeEngine:
+    """AutoencoderKL encoder on the HIP engine for one image size (smi_vae_*): image -> posterior moments."""
+
+    def __init__(self, cfg, dtype: torch.dtype, state: dict, batch: int, h: int, w: int, device):
+        c = VaeConfigC()
+        c.dtype = DTYPE_CODE[dtype]
+        c.in_channels, c.latent_channels = cfg.in_channels, cfg.latent_channels
+        c.n_levels = len(cfg.block_out_channels)
+        for i, v in enumerate(cfg.block_out_channels):
+            c.block_out_channels[i] = v
+        c.layers_per_block, c.norm_num_groups = cfg.layers_per_block, cfg.norm_num_groups
+        self.cfg_c, self.batch, self.h, self.w = c, batch, h, w
+        self.latent_channels = cfg.latent_channels
+        self.down = 2 ** (len(cfg.block_out_channels) - 1)
+        out = C.c_size_t(0)
+        check(lib().smi_vae_workspace_bytes(C.byref(c), batch, h, w, C.byref(out)), "smi_vae_workspace_bytes")
+        self.workspace = torch.empty(out.value, dtype=torch.uint8, device=device)
+        warr, self._keep = _weight_table(state, dtype, self.workspace.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.workspace.device):
+            check(lib().smi_vae_create(C.byref(c), warr, len(state), batch, h, w, ptr(self.workspace), out.value,
+                                       stream_ptr(), C.byref(handle)), "smi_vae_create")
+        self.handle = handle
+
+    def moments(self, image: torch.Tensor) -> torch.Tensor:
+        n = image.shape[0]
+        out = torch.empty((n, 2 * self.latent_channels, self.h // self.down, self.w // self.down), dtype=torch.float32,
+                          device=image.device)
+        check(lib().smi_vae_encode(self.handle, n, ptr(image), ptr(out)), "smi_vae_encode")
+        return out
 
     def close(self):
         if getattr(self, "handle", None):

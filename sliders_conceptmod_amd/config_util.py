@@ -65,7 +65,18 @@ def parse_precision(precision: str) -> torch.dtype:
     raise ValueError(f"Invalid precision type: {precision}")
 
 
+def resolve_data_path(path: str) -> str:
+    """`data/...` paths (the CLI defaults and the shipped configs' prompts_file) are looked up in the working directory
+    first, as the reference does, then next to this package (sliders_conceptmod_amd/data/)."""
+    import os
+    if os.path.exists(path):
+        return path
+    alt = os.path.join(os.path.dirname(os.path.abspath(__file__)), path)
+    return alt if os.path.exists(alt) else path
+
+
 def load_config_from_yaml(config_path: str):
+    config_path = resolve_data_path(config_path)
     with open(config_path, "r") as fh:
         raw = yaml.safe_load(fh)  # plain data only: nothing in the file is executed
     root = RootConfig(**raw)

@@ -166,6 +166,39 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, T*
     out[(int64_t)n * C + c] = from_f<T>(((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * mul);
   }
 }
+// one workgroup per row: max, sum of exp, normalised write (three passes over a row that sits in L2)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, T* __restrict__ P, int cols,
+                                                           float scale) {
+  __shared__ float sh[4];
+  const float* s = S + (int64_t)blockIdx.x * cols;
+  T* p = P + (int64_t)blockIdx.x * cols;
+  float m = -3.0e38f;
+  for (int i = threadIdx.x; i < cols; i += 256) m = fmaxf(m, s[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) * scale;
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) sum += __expf(s[i] * scale - m);
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.f / ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  for (int i = threadIdx.x; i < cols; i += 256) p[i] = from_f<T>(__expf(s[i] * scale - m) * inv);
+}
+template <typename T>
+__global__ void chan_mix_kernel(const float* __restrict__ x, const T* __restrict__ W, const T* __restrict__ b,
+                                float* __restrict__ y, int64_t M, int C) {
+  GSTRIDE(i, M * C) {
+    const int j = (int)(i % C);
+    const int64_t m = i / C;
+    float acc = to_f(b[j]);
+    for (int k = 0; k < C; ++k) acc += x[m * C + k] * to_f(W[j * C + k]);
+    y[i] = acc;
+  }
+}
 // dst[m][0..cpad) = (T)(src[m][0..cols) * mul), zero beyond cols   (fp32 rank-r rows -> a 64-channel MFMA operand)
 template <typename T>
 __global__ void f32_to_padded_kernel(const float* __restrict__ src, int lds, int cols, T* __restrict__ dst, int cpad,
@@ -439,6 +472,24 @@ int launch_sched_affine(float* x, const float* eps, const float* noise, float c_
   return 0;
 }
 
+int launch_softmax_rows(int dtype, const float* S, void* P, int rows, int cols, float scale, hipStream_t stream) {
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(softmax_rows_kernel<f16>, dim3(rows), dim3(256), 0, stream, S, (f16*)P, cols, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16>, dim3(rows), dim3(256), 0, stream, S, (bf16*)P, cols, scale);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_chan_mix(int dtype, const float* x, const void* W, const void* b, float* y, int64_t M, int C,
+                    hipStream_t stream) {
+  const int grid = ew_grid(M * C);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(chan_mix_kernel<f16>, dim3(grid), dim3(256), 0, stream, x, (const f16*)W, (const f16*)b, y, M, C);
+  else
+    hipLaunchKernelGGL(chan_mix_kernel<bf16>, dim3(grid), dim3(256), 0, stream, x, (const bf16*)W, (const bf16*)b, y, M, C);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
 int launch_colsum(int dtype, const void* x, void* out, int Nb, int HW, int C, float mul, hipStream_t stream) {
   dim3 grid(cdiv(C, 64), Nb);
   if (dtype == DT_F16)

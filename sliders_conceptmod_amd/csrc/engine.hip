@@ -142,6 +142,7 @@ struct Conv {
   const void* b = nullptr;
   int Cin = 0, Cout = 0;
   int mode = 0;  // 0 stride 1, 1 stride-2 downsample, 2 nearest-2x upsample + conv
+  int pad = 1;   // 0: the VAE encoder's downsampler (input padded (0,1,0,1), stride 2)
   // c3lier LoRA (T/lora.py:100-114): 3x3 down conv [r][Cin][3][3] with the layer's stride / padding, then 1x1 up [Cout][r]
   std::string name;
   int nsite = 0, rank = 0, rows_pad = 0;
@@ -162,6 +163,7 @@ struct Resnet {
   Conv c1, c2;
   Lin temb, sc;
   bool has_sc = false;
+  bool has_temb = true;  // false in the VAE encoder
 };
 struct TBlock {
   Norm n1, n2, n3;
@@ -480,10 +482,10 @@ struct smi_engine {
   }
   void* pack_alloc(size_t bytes) { return wpack.alloc(bytes); }
 
-  void transpose_into(const void* src, void* dst, int R, int C, int ldd, int col0) {
+  void transpose_into(const void* src, void* dst, int R, int C, int ldd, int col0, bool packing = true) {
     if (dry || err || !src) return;
     const int grid = ((R + 63) / 64) * ((C + 63) / 64);
-    ++pack_launches;
+    if (packing) ++pack_launches;
     if (dtype == DT_F16)
       hipLaunchKernelGGL(pack_transpose_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, (f16*)dst, R, C, ldd, col0);
     else
@@ -671,16 +673,18 @@ struct smi_engine {
     check_shape(name + ".weight", {C});
     return n;
   }
-  Resnet make_resnet(const std::string& name, int Cin, int Cout) {
+  // grad: the block lies on a gradient path (gradient filter packs, transposed shortcut); eps 1e-5 UNet / 1e-6 VAE
+  Resnet make_resnet(const std::string& name, int Cin, int Cout, bool temb = true, float eps = 1e-5f, bool grad = true) {
     Resnet r;
     const int ted = cfg.block_out_channels[0] * 4;
-    r.n1 = make_norm(name + ".norm1", Cin, 1e-5f);
-    r.c1 = make_conv(name + ".conv1", Cin, Cout, 0, true);
-    r.temb = make_lin(name + ".time_emb_proj", ted, Cout, true, false, true);
-    r.n2 = make_norm(name + ".norm2", Cout, 1e-5f);
-    r.c2 = make_conv(name + ".conv2", Cout, Cout, 0, true);
+    r.n1 = make_norm(name + ".norm1", Cin, eps);
+    r.c1 = make_conv(name + ".conv1", Cin, Cout, 0, grad);
+    r.has_temb = temb;
+    if (temb) r.temb = make_lin(name + ".time_emb_proj", ted, Cout, true, false, true);
+    r.n2 = make_norm(name + ".norm2", Cout, eps);
+    r.c2 = make_conv(name + ".conv2", Cout, Cout, 0, grad);
     r.has_sc = Cin != Cout;
-    if (r.has_sc) r.sc = make_lin(name + ".conv_shortcut", Cin, Cout, true, true);
+    if (r.has_sc) r.sc = make_lin(name + ".conv_shortcut", Cin, Cout, true, grad);
     return r;
   }
   Transformer make_transformer(const std::string& name, int C, int heads, int layers) {
@@ -1181,6 +1185,7 @@ struct smi_engine {
     p.Hout = Hout;
     p.Wout = Wout;
     p.stride = c.mode == 1 ? 2 : 1;
+    p.pad = c.pad;
     p.upsample = c.mode == 2 ? 1 : 0;
     if (rowvec) {
       p.rowvec = rowvec->p;
@@ -1393,7 +1398,7 @@ struct smi_engine {
 
   Ten* resnet(Ten* x, const Resnet& r, Ten* temb_act) {
     Ten* h = groupnorm(x, r.n1, true);
-    Ten* t = linear(temb_act, r.temb);
+    Ten* t = r.has_temb ? linear(temb_act, r.temb) : nullptr;
     h = conv3x3(h, r.c1, t, nullptr);
     h = groupnorm(h, r.n2, true);
     Ten* sc = r.has_sc ? linear(x, r.sc) : x;
@@ -1424,6 +1429,174 @@ struct smi_engine {
       h = linear(gg, tb.ff2, h);
     }
     return linear(h, t.proj_out, x);
+  }
+
+  // ---------------------------------------------------------------------------------------------------------
+  // AutoencoderKL encoder (image sliders: I/train_util.py:213-222 `vae.encode(image).latent_dist`), forward only.
+  // Same kernels as the UNet: GroupNorm(+SiLU), implicit-GEMM 3x3 convs (the downsampler with its (0,1,0,1) padding as
+  // `pad = 0`), 1x1 shortcuts as GEMMs.  The mid block's attention is ONE head of width 512 over all pixels: run as
+  // materialised GEMMs (scores in fp32, row softmax, P V), a few GFLOP per image.
+  // ---------------------------------------------------------------------------------------------------------
+  bool is_vae = false;
+  smi_vae_config vcfg{};
+  struct VLevel {
+    std::vector<Resnet> res;
+    bool has_samp = false;
+    Conv samp;
+  };
+  std::vector<VLevel> v_down;
+  Resnet v_mid0, v_mid1;
+  Norm v_attn_norm, v_norm_out;
+  Lin v_qkv, v_o;
+  Conv v_conv_in, v_conv_out;
+  const void* v_quant_w = nullptr;
+  const void* v_quant_b = nullptr;
+
+  void build_vae() {
+    const int L = vcfg.n_levels;
+    const int* boc = vcfg.block_out_channels;
+    {
+      v_conv_in.Cin = 64;
+      v_conv_in.Cout = boc[0];
+      v_conv_in.b = Wd("encoder.conv_in.bias");
+      check_shape("encoder.conv_in.weight", {boc[0], vcfg.in_channels, 3, 3});
+      void* wp = pack_alloc((size_t)boc[0] * 9 * 64 * esz());
+      pack_conv_into(Wd("encoder.conv_in.weight"), wp, boc[0], vcfg.in_channels, 0, 64);
+      v_conv_in.Wp = wp;
+    }
+    v_down.resize(L);
+    int ch = boc[0];
+    for (int i = 0; i < L; ++i) {
+      const std::string b = "encoder.down_blocks." + std::to_string(i);
+      for (int j = 0; j < vcfg.layers_per_block; ++j)
+        v_down[i].res.push_back(make_resnet(b + ".resnets." + std::to_string(j), j == 0 ? ch : boc[i], boc[i], false, 1e-6f, false));
+      ch = boc[i];
+      v_down[i].has_samp = i != L - 1;
+      if (v_down[i].has_samp) {
+        v_down[i].samp = make_conv(b + ".downsamplers.0.conv", ch, ch, 1, false);
+        v_down[i].samp.pad = 0;
+      }
+    }
+    v_mid0 = make_resnet("encoder.mid_block.resnets.0", ch, ch, false, 1e-6f, false);
+    v_attn_norm = make_norm("encoder.mid_block.attentions.0.group_norm", ch, 1e-6f);
+    v_qkv = make_fused("encoder.mid_block.attentions.0", {"to_q", "to_k", "to_v"}, ch, ch, false);
+    {  // fused q|k|v bias
+      char* bq = (char*)pack_alloc((size_t)3 * ch * esz());
+      const char* parts[3] = {"to_q", "to_k", "to_v"};
+      for (int i = 0; i < 3; ++i) {
+        const void* src = Wd(std::string("encoder.mid_block.attentions.0.") + parts[i] + ".bias");
+        if (!dry && !err && src)
+          (void)hipMemcpyAsync(bq + (size_t)i * ch * esz(), src, (size_t)ch * esz(), hipMemcpyDeviceToDevice, stream);
+      }
+      v_qkv.b = bq;
+    }
+    v_o = make_lin("encoder.mid_block.attentions.0.to_out.0", ch, ch, true, false);
+    v_mid1 = make_resnet("encoder.mid_block.resnets.1", ch, ch, false, 1e-6f, false);
+    v_norm_out = make_norm("encoder.conv_norm_out", ch, 1e-6f);
+    v_conv_out = make_conv("encoder.conv_out", ch, 2 * vcfg.latent_channels, 0, false);
+    v_quant_w = Wd("quant_conv.weight");
+    v_quant_b = Wd("quant_conv.bias");
+    check_shape("quant_conv.weight", {2 * vcfg.latent_channels, 2 * vcfg.latent_channels, 1, 1});
+    gscale = (float*)pack_alloc(256 * sizeof(float));
+    finish_lora();
+  }
+
+  // image f32 [n, 3, h, w] in [-1, 1]  ->  moments f32 [n, 2 * latent, h/8, w/8] (mean | logvar, before the clamp)
+  int forward_vae(int n, const float* image, float* moments_out) {
+    n_ad = 0;
+    cur = &arena[0];
+    cur->reset();
+    tens = &tens_[0];
+    tens->clear();
+    saving = false;
+    lora_down = lora_up = nullptr;
+    mult = 0.f;
+    const int H = lat_h, Wd_ = lat_w;  // image size for this engine kind
+    Ten* x0 = new_ten((int64_t)n * H * Wd_, 64, n, H, Wd_);
+    RUN(launch_nchw_to_nhwc(dtype, image, 1, x0->p, n, vcfg.in_channels, H * Wd_, 64, 1.f, stream));
+    Ten* h = conv3x3(x0, v_conv_in, nullptr, nullptr);
+    for (auto& lv : v_down) {
+      for (auto& r : lv.res) h = resnet(h, r, nullptr);
+      if (lv.has_samp) h = conv3x3(h, lv.samp, nullptr, nullptr);
+    }
+    h = resnet(h, v_mid0, nullptr);
+    {  // single-head attention over the pixels, with its own GroupNorm and residual
+      const int C = h->cols, N = h->H * h->W;
+      Ten* nrm = groupnorm(h, v_attn_norm, false);
+      Ten* qkv = linear(nrm, v_qkv);
+      Ten* o = new_ten(h->rows, C, h->n, h->H, h->W);
+      const float sc = 1.f / sqrtf((float)C);
+      for (int i = 0; i < n; ++i) {
+        const char* base = (const char*)qkv->p + (size_t)i * N * 3 * C * esz();
+        float* S = alloc_f32((size_t)N * N);
+        void* P = alloc_t(N, N);
+        void* Vt = alloc_t(C, N);
+        GemmParams g;
+        g.dtype = dtype;
+        g.A = base;
+        g.lda = 3 * C;
+        g.W = base + (size_t)C * esz();  // K rows, row stride 3C: not a dense [N, C] operand -> copy below
+        // the GEMM's W operand is dense [N_out, K]: K (and V) are column blocks of the fused tensor, so stage them
+        void* Kd = alloc_t(N, C);
+        RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, base + (size_t)C * esz(), 3 * C, Kd, C, 0, N, C, stream));
+        g.W = Kd;
+        g.C = S;
+        g.ldc = N;
+        g.out_f32 = 1;
+        g.M = N;
+        g.N = N;
+        g.K = C;
+        RUNP(SMI_PROF_ATTN, 2.0 * N * N * C, 0.0, launch_gemm(g, stream));
+        RUNP(SMI_PROF_ATTN, 0.0, 0.0, launch_softmax_rows(dtype, S, P, N, N, sc, stream));
+        void* Vd = alloc_t(N, C);
+        RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_copy_cols(dtype, base + (size_t)2 * C * esz(), 3 * C, Vd, C, 0, N, C, stream));
+        transpose_into(Vd, Vt, N, C, N, 0, false);
+        GemmParams pv;
+        pv.dtype = dtype;
+        pv.A = P;
+        pv.lda = N;
+        pv.W = Vt;
+        pv.C = (char*)o->p + (size_t)i * N * C * esz();
+        pv.ldc = C;
+        pv.M = N;
+        pv.N = C;
+        pv.K = N;
+        RUNP(SMI_PROF_ATTN, 2.0 * N * N * C, 0.0, launch_gemm(pv, stream));
+      }
+      h = linear(o, v_o, h);
+    }
+    h = resnet(h, v_mid1, nullptr);
+    Ten* hn = groupnorm(h, v_norm_out, true);
+    const int C2 = 2 * vcfg.latent_channels;
+    const int Ho = hn->H, Wo = hn->W;
+    Ten* y = new_ten((int64_t)n * Ho * Wo, C2, n, Ho, Wo, sizeof(float));
+    {
+      GemmParams p;
+      p.dtype = dtype;
+      p.conv = 1;
+      p.A = hn->p;
+      p.W = v_conv_out.Wp;
+      p.C = y->p;
+      p.ldc = C2;
+      p.out_f32 = 1;
+      p.M = (int)y->rows;
+      p.N = C2;
+      p.K = 9 * v_conv_out.Cin;
+      p.bias = v_conv_out.b;
+      p.Nb = n;
+      p.Hin = p.Hout = Ho;
+      p.Win = p.Wout = Wo;
+      p.Cin = v_conv_out.Cin;
+      RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 0.0, launch_gemm(p, stream));
+    }
+    float* q = alloc_f32((size_t)y->rows * C2);
+    RUN(launch_chan_mix(dtype, (const float*)y->p, v_quant_w, v_quant_b, q, y->rows, C2, stream));
+    RUN(launch_nhwc_to_nchw_f32(q, moments_out, n, C2, Ho * Wo, stream));
+    if (cur->overflow && !dry) {
+      set_error("workspace too small for this call (needs %zu bytes, has %zu)", cur->peak, cur->cap);
+      return -3;
+    }
+    return err ? -1 : 0;
   }
 
   // ---------------------------------------------------------------------------------------------------------
@@ -1776,6 +1949,90 @@ void smi_destroy(smi_engine* e) {
   delete e;
 }
 
+// ---- AutoencoderKL encoder engine ------------------------------------------------------------------------------------
+static int check_vae_cfg(const smi_vae_config* c, int batch, int h, int w) {
+  SMI_CHECK(c != nullptr, "config is NULL");
+  SMI_CHECK(c->dtype == SMI_DTYPE_F16 || c->dtype == SMI_DTYPE_BF16, "dtype must be f16 (0) or bf16 (1)");
+  SMI_CHECK(c->n_levels >= 1 && c->n_levels <= SMI_MAX_LEVELS && c->in_channels >= 1 && c->in_channels <= 16 &&
+                c->latent_channels >= 1 && c->latent_channels <= 8 && c->layers_per_block >= 1,
+            "VAE config out of range");
+  for (int i = 0; i < c->n_levels; ++i)
+    SMI_CHECK(c->block_out_channels[i] % 64 == 0 && c->block_out_channels[i] % c->norm_num_groups == 0,
+              "VAE block_out_channels must be multiples of 64 and of norm_num_groups");
+  const int f = 1 << (c->n_levels - 1);
+  SMI_CHECK(batch > 0 && h > 0 && w > 0 && h % f == 0 && w % f == 0, "image size must be a multiple of %d", f);
+  return 0;
+}
+static void vae_setup(smi_engine* e, const smi_vae_config* cfg, const smi_weight* weights, int n_weights, int batch, int h,
+                      int w) {
+  e->is_vae = true;
+  e->vcfg = *cfg;
+  e->dtype = cfg->dtype;
+  e->cfg.norm_num_groups = cfg->norm_num_groups;
+  e->cfg.block_out_channels[0] = cfg->block_out_channels[0];
+  e->max_n = batch;
+  e->lat_h = h;
+  e->lat_w = w;
+  for (int i = 0; i < n_weights; ++i) e->wmap[weights[i].name] = &weights[i];
+}
+static int vae_plan(const smi_vae_config* cfg, int batch, int h, int w, size_t out[2]) {
+  smi_engine e;
+  e.dry = true;
+  vae_setup(&e, cfg, nullptr, 0, batch, h, w);
+  e.build_vae();
+  if (e.err) return -1;
+  out[0] = align_up(e.wpack.peak, 4096);
+  e.forward_vae(batch, nullptr, nullptr);
+  out[1] = align_up(e.arena[0].peak, 4096);
+  return e.err ? -1 : 0;
+}
+
+int smi_vae_workspace_bytes(const smi_vae_config* cfg, int batch, int h, int w, size_t* bytes) {
+  if (check_vae_cfg(cfg, batch, h, w)) return -1;
+  SMI_CHECK(bytes != nullptr, "bad arguments");
+  size_t r[2];
+  if (vae_plan(cfg, batch, h, w, r)) return -1;
+  *bytes = r[0] + r[1] + 2 * 4096;
+  return 0;
+}
+
+int smi_vae_create(const smi_vae_config* cfg, const smi_weight* weights, int n_weights, int batch, int h, int w,
+                   void* workspace, size_t workspace_bytes, void* stream, smi_engine** out) {
+  if (check_vae_cfg(cfg, batch, h, w)) return -1;
+  SMI_CHECK(out && workspace && weights && n_weights > 0, "bad arguments");
+  size_t r[2];
+  if (vae_plan(cfg, batch, h, w, r)) return -1;
+  SMI_CHECK(r[0] + r[1] + 2 * 4096 <= workspace_bytes, "workspace too small: need %zu bytes, got %zu",
+            r[0] + r[1] + 2 * 4096, workspace_bytes);
+  smi_engine* e = new smi_engine();
+  e->stream = (hipStream_t)stream;
+  vae_setup(e, cfg, weights, n_weights, batch, h, w);
+  char* base = (char*)align_up((size_t)workspace, 4096);
+  e->ws = (char*)workspace;
+  e->ws_bytes = workspace_bytes;
+  e->wpack.base = base;
+  e->wpack.cap = r[0];
+  e->arena[0].base = base + r[0];
+  e->arena[0].cap = r[1];
+  e->build_vae();
+  if (!e->err) (void)hipStreamSynchronize(e->stream);
+  if (e->err || hipGetLastError() != hipSuccess) {
+    if (!e->err) set_error("HIP error while packing the VAE weights");
+    delete e;
+    return -1;
+  }
+  e->wmap.clear();
+  *out = e;
+  return 0;
+}
+
+int smi_vae_encode(smi_engine* e, int n, const float* image, float* moments_out) {
+  SMI_CHECK(e && e->is_vae && image && moments_out, "smi_vae_encode: NULL argument or not a VAE engine");
+  SMI_CHECK(n >= 1 && n <= e->max_n, "batch %d outside [1, %d] the engine was created for", n, e->max_n);
+  e->err = false;
+  return e->forward_vae(n, image, moments_out);
+}
+
 int smi_weights_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, size_t* bytes) {
   if (check_cfg(cfg)) return -1;
   SMI_CHECK(bytes != nullptr, "bad arguments");
@@ -1800,6 +2057,7 @@ int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ct
                size_t arena_bytes) {
   SMI_CHECK(e && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
             "bad arguments");
+  SMI_CHECK(!e->is_vae, "smi_replan: VAE engines are created per image size");
   size_t r[3];
   if (plan(&e->cfg, e->sites.data(), (int)e->sites.size(), batch, batch_adapted, h, w, ctx_len, r)) return -1;
   char* base = arena ? (char*)align_up((size_t)arena, 4096) : e->arena_home;
@@ -1840,6 +2098,7 @@ int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* s
                              const void* text_embeds, const float* time_ids, const float* lora_down_flat,
                              const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out) {
   SMI_CHECK(e && sample && ctx && eps_out, "NULL argument");
+  SMI_CHECK(!e->is_vae, "this engine is a VAE encoder (use smi_vae_encode)");
   SMI_CHECK(n >= 1 && n <= e->max_n, "batch %d outside [1, %d] the engine was created for", n, e->max_n);
   SMI_CHECK(n_adapted >= 0 && n_adapted <= n && n_adapted <= e->max_n_ad,
             "adapted batch %d outside [0, min(%d, %d)]", n_adapted, n, e->max_n_ad);
@@ -1861,6 +2120,7 @@ int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, 
 
 int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat, float* d_lora_up_flat) {
   SMI_CHECK(e && d_eps && d_lora_down_flat && d_lora_up_flat, "NULL argument");
+  SMI_CHECK(!e->is_vae, "this engine is a VAE encoder: it has no backward");
   e->err = false;
   return e->backward(d_eps, d_lora_down_flat, d_lora_up_flat);
 }

@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
           ok = (ty >= 0) && (tx >= 0) && (iy * p.stride == ty) && (ix * p.stride == tx) && (iy < p.Hin) &&
                (ix < p.Win);
         } else {
-          iy = crow[i].oy * p.stride + ky - 1;
-          ix = crow[i].ox * p.stride + kx - 1;
+          iy = crow[i].oy * p.stride + ky - p.pad;
+          ix = crow[i].ox * p.stride + kx - p.pad;
           if (p.upsample) {
             ok = (iy >= 0) && (ix >= 0) && (iy < 2 * p.Hin) && (ix < 2 * p.Win);
             iy >>= 1;

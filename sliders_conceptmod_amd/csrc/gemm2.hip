@@ -198,8 +198,8 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
           ok = (ty >= 0) && (tx >= 0) && (iy * p.stride == ty) && (ix * p.stride == tx) && (iy < p.Hin) &&
                (ix < p.Win);
         } else {
-          iy = c_oy[j] * p.stride + ky - 1;
-          ix = c_ox[j] * p.stride + kx - 1;
+          iy = c_oy[j] * p.stride + ky - p.pad;
+          ix = c_ox[j] * p.stride + kx - p.pad;
           if (p.upsample) {
             ok = (iy >= 0) && (ix >= 0) && (iy < 2 * p.Hin) && (ix < 2 * p.Win);
             iy >>= 1;

@@ -49,7 +49,8 @@ struct GemmParams {
   // implicit-GEMM 3x3 convolution (pad 1)
   int conv = 0;
   int Nb = 0, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0;
-  int stride = 1;      // forward: in = out*stride + k - 1
+  int stride = 1;      // forward: in = out*stride + k - pad
+  int pad = 1;         // 1 everywhere in the UNet; 0 for the VAE encoder's (0,1,0,1)-padded stride-2 downsampler
   int upsample = 0;    // nearest-2x upsample of the input folded into the gather
   int transposed = 0;  // gradient of a strided conv: out = (in + 1 - k) / stride
 };
@@ -124,6 +125,11 @@ int launch_nhwc_to_nchw_f32(const float* src, float* dst, int Nb, int C, int HW,
 int launch_timestep_embed(int dtype, const float* vals, void* out, int n, int dim, hipStream_t stream);
 // dx[n,h,w,c] = sum_{2x2} du[n,2h+a,2w+b,c]
 int launch_pool2x2_sum(int dtype, const void* du, void* dx, int Nb, int H, int W, int C, hipStream_t stream);
+// P[r][:] = softmax(scale * S[r][:]) for rows of fp32 scores (materialised attention of the VAE's single 512-wide head)
+int launch_softmax_rows(int dtype, const float* S, void* P, int rows, int cols, float scale, hipStream_t stream);
+// y[m][j] = b[j] + sum_i x[m][i] W[j][i] on fp32 rows of width C <= 16 (the VAE's 1x1 quant_conv), W / b of dtype T
+int launch_chan_mix(int dtype, const float* x, const void* W, const void* b, float* y, int64_t M, int C,
+                    hipStream_t stream);
 // out[n][c] = mul * sum over the HW rows of sample n of x[n][hw][c]   (deterministic)
 int launch_colsum(int dtype, const void* x, void* out, int Nb, int HW, int C, float mul, hipStream_t stream);
 // dst[M][cpad] (T) = src[M][0..cols) (fp32, row stride lds) * mul, zero padded

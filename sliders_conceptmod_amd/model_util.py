@@ -191,6 +191,35 @@ def _unet_from_dir(path: str, dtype):
     return unet
 
 
+def load_vae(pretrained_model_name_or_path: str, xl: bool = False):
+    """The AutoencoderKL the image-slider scripts get next to the UNet (I/model_util.py:75,179): `synthetic://...`
+    builds the SD / SD-XL VAE encoder architecture with seeded weights; a local diffusers directory is read from its
+    `vae/` sub-folder with the safetensors loader."""
+    import json
+    import os
+    from . import vae as PV
+    name = pretrained_model_name_or_path
+    if name.startswith("synthetic://"):
+        if "tiny" in name:
+            cfg = PV.VAEConfig(block_out_channels=(64, 128, 128, 128), norm_num_groups=16,
+                               scaling_factor=0.13025 if xl else 0.18215)
+        else:
+            cfg = PV.sdxl_vae_config() if xl else PV.sd_vae_config()
+        return PV.init_synthetic_(PV.AutoencoderKL(cfg), seed=7)
+    if os.path.isdir(name):
+        from safetensors.torch import load_file
+        cj = json.load(open(os.path.join(name, "vae", "config.json")))
+        cfg = PV.VAEConfig(in_channels=cj.get("in_channels", 3), latent_channels=cj.get("latent_channels", 4),
+                           block_out_channels=tuple(cj["block_out_channels"]),
+                           layers_per_block=cj.get("layers_per_block", 2),
+                           norm_num_groups=cj.get("norm_num_groups", 32),
+                           scaling_factor=cj.get("scaling_factor", 0.18215))
+        vae = PV.AutoencoderKL(cfg)
+        vae.load_state_dict(load_file(os.path.join(name, "vae", "diffusion_pytorch_model.safetensors")))
+        return vae
+    raise ValueError(f"cannot load a VAE from '{name}': pass a local diffusers directory or synthetic://sd1x | sdxl")
+
+
 def load_models(pretrained_model_name_or_path: str, scheduler_name: str = "ddim", v2: bool = False,
                 v_pred: bool = False, weight_dtype=torch.float32, xl: bool = False):
     """Returns (tokenizer(s), text_encoder(s), unet, noise_scheduler) like the reference (model_util.py:112-137,

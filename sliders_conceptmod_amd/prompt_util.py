@@ -110,7 +110,8 @@ def load_prompts_from_yaml(path, attributes: Sequence[str] = ()):
     """Reads prompts.yaml; with attributes, every entry is repeated once per attribute with the attribute prefixed to
     each prompt it has (the reference prefixes `negative` unconditionally and KeyErrors on its own shipped
     prompts.yaml, prompt_util.py:191 -- a missing key is simply skipped here)."""
-    with open(path, "r") as fh:
+    from .config_util import resolve_data_path
+    with open(resolve_data_path(path), "r") as fh:
         entries = yaml.safe_load(fh)
     if not entries:
         raise ValueError("prompts file is empty")

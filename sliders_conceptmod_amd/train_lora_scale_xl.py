@@ -8,10 +8,10 @@ noisy latents = scheduler.add_noise(latent, noise, t) (I/train_util.py:200-235);
 gradients accumulate, one optimizer.step().  (The reference also runs two frozen passes whose results the loss never
 uses, :263-308; they are skipped here -- they cannot change the result.)
 
-Scope note: the reference encodes the image pair with the VAE every step.  The VAE (and the CLIP front end) is a
-"next" row of this tier, so this trainer consumes PRE-ENCODED latents: `--folder_main` holds, per scale folder given in
-`--folders` (e.g. "bigsize,smallsize") a `<name>.pt` / `.safetensors` tensor [4, h, w] per image (already multiplied by
-the VAE scaling factor).  Everything downstream of the encode is the reference's arithmetic."""
+Data: `--folder_main` holds one sub-folder per scale (`--folders`, e.g. "bigsize,smallsize"), each with the same file
+names.  Image files (.png / .jpg / .jpeg / .webp) are resized and VAE-encoded every step exactly as the reference does
+(`train_util.get_noisy_image`, I/train_lora-scale-xl.py:216-247) on the HIP VAE encoder; `<name>.pt` / `.safetensors`
+tensors [4, h, w] are taken as PRE-ENCODED latents (already multiplied by the VAE scaling factor)."""
 import argparse
 import os
 import random
@@ -56,7 +56,12 @@ def _load_latent(path):
     return torch.load(path, weights_only=True)
 
 
-def train(config, prompts, device, folder_main, folders, scales, models=None, rank=4):
+_IMAGE_EXT = (".png", ".jpg", ".jpeg", ".webp")  # I/train_lora-scale-xl.py:217
+
+
+def train(config, prompts, device, folder_main, folders, scales, models=None, rank=4, vae=None, image_size=None):
+    """`vae` (an AutoencoderKL, default: loaded next to the UNet) is only needed when the folders hold image files;
+    `image_size` is what the pairs are resized to (the reference hard-codes (512, 512), I/train_lora-scale-xl.py:220)."""
     weight_dtype = config_util.parse_precision(config.train.precision)
     tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
         config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=True)
@@ -92,6 +97,15 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
         if -s not in folder_of:
             raise ValueError(f"scale {s:g} has no counterpart {-s:g} in --scales: the two-sided step needs both")
     names = sorted(os.listdir(os.path.join(folder_main, folder_of[scales[0]])))
+    images = [n for n in names if n.lower().endswith(_IMAGE_EXT)]
+    if images:
+        names = images
+        if vae is None:
+            vae = model_util.load_vae(config.pretrained_model.name_or_path, xl=True)
+        vae.to(device, dtype=weight_dtype)
+        vae.requires_grad_(False)
+        vae.eval()
+    size = image_size or (512, 512)
     save_path = Path(config.save.path)
     save_dtype = config_util.parse_precision(config.train.precision)
     for i in tqdm(range(config.train.iterations), disable=rank_ != 0):
@@ -101,17 +115,27 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
         scale_to_look = abs(random.choice(scales))
         f_low, f_high = folder_of[-scale_to_look], folder_of[scale_to_look]
         name = names[(random.randint(0, len(names) - 1) + rank_) % len(names)]  # ranks take different pairs
-        lat_low = _load_latent(os.path.join(folder_main, f_low, name)).unsqueeze(0).float()
-        lat_high = _load_latent(os.path.join(folder_main, f_high, name)).unsqueeze(0).float()
         seed = random.randint(0, 2 * 15)
-        t = noise_scheduler.timesteps[timesteps_to]
-        g = torch.Generator().manual_seed(seed)
-        noise_low = torch.randn(lat_low.shape, generator=g)
-        g = torch.Generator().manual_seed(seed)
-        noise_high = torch.randn(lat_high.shape, generator=g)
-        nl = noise_scheduler.add_noise(lat_low, noise_low, t).to(device)
-        nh = noise_scheduler.add_noise(lat_high, noise_high, t).to(device)
-        h, w = lat_low.shape[-2] * 8, lat_low.shape[-1] * 8
+        if images:  # the reference's path: resize, VAE-encode and noise both images with the same seed (:220-247)
+            from PIL import Image
+            pair = []
+            for f in (f_low, f_high):
+                img = Image.open(os.path.join(folder_main, f, name)).resize(size)
+                pair.append(train_util.get_noisy_image(img, vae, torch.manual_seed(seed), unet, noise_scheduler,
+                                                       start_timesteps=0, total_timesteps=timesteps_to))
+            (nl, noise_low), (nh, noise_high) = pair
+            h, w = size[1], size[0]
+        else:
+            lat_low = _load_latent(os.path.join(folder_main, f_low, name)).unsqueeze(0).float()
+            lat_high = _load_latent(os.path.join(folder_main, f_high, name)).unsqueeze(0).float()
+            t = noise_scheduler.timesteps[timesteps_to]
+            g = torch.Generator().manual_seed(seed)
+            noise_low = torch.randn(lat_low.shape, generator=g)
+            g = torch.Generator().manual_seed(seed)
+            noise_high = torch.randn(lat_high.shape, generator=g)
+            nl = noise_scheduler.add_noise(lat_low, noise_low, t).to(device)
+            nh = noise_scheduler.add_noise(lat_high, noise_high, t).to(device)
+            h, w = lat_low.shape[-2] * 8, lat_low.shape[-1] * 8
         tid = train_util.get_add_time_ids(h, w, dtype=torch.float32).to(device)
         noise_scheduler.set_timesteps(1000)
         cur_t = noise_scheduler.timesteps[int(timesteps_to * 1000 / config.train.max_denoising_steps)]

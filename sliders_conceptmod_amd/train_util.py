@@ -76,6 +76,26 @@ def diffusion_xl(unet, scheduler, latents, text_embeddings, add_text_embeddings,
     return latents
 
 
+@torch.no_grad()
+def get_noisy_image(img, vae, generator, unet, scheduler, total_timesteps: int = 1000, start_timesteps=0, **kwargs):
+    """Image-slider front end (trainscripts/imagesliders/train_util.py:200-235), same signature and order of operations:
+    preprocess -> vae.encode(image).latent_dist.sample(None) -> x vae.config.scaling_factor -> noise = randn(shape,
+    generator) -> scheduler.add_noise(latents, noise, scheduler.timesteps[total_timesteps : total_timesteps + 1]).
+    Returns (noised latents, noise).  `unet`, `start_timesteps` are unused there too."""
+    from .vae import VaeImageProcessor
+    vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+    image = VaeImageProcessor(vae_scale_factor=vae_scale_factor).preprocess(img).to(vae.device)
+    init_latents = vae.encode(image).latent_dist.sample(None)
+    init_latents = vae.config.scaling_factor * init_latents
+    shape = init_latents.shape
+    # randn_tensor(shape, generator=generator, device=device): a CPU generator draws on the host and the result is moved
+    gdev = "cpu" if generator is None or generator.device.type == "cpu" else init_latents.device
+    noise = torch.randn(shape, generator=generator, device=gdev, dtype=init_latents.dtype).to(init_latents.device)
+    timestep = scheduler.timesteps[total_timesteps:total_timesteps + 1]
+    init_latents = scheduler.add_noise(init_latents, noise, timestep)
+    return init_latents, noise
+
+
 def get_add_time_ids(height: int, width: int, dynamic_crops: bool = False, dtype: torch.dtype = torch.float32):
     if dynamic_crops:
         random_scale = torch.rand(1).item() * 2 + 1

@@ -162,8 +162,8 @@ def test_workspace_plan_dry_run(libpath, model, batch, hw):
 def test_engine_rejects_unsupported_lora_target(libpath):
     cfg = pcfg(OU.tiny_sd1x_config())
     cc = _native.make_config(cfg, torch.float16)
-    with pytest.raises(_native.SmiError, match="not an attention projection"):
-        _native.workspace_bytes(cc, [{"target": "down_blocks.0.resnets.0.time_emb_proj", "off_down": 0, "off_up": 0,
+    with pytest.raises(_native.SmiError, match="not a layer this engine adapts"):
+        _native.workspace_bytes(cc, [{"target": "time_embedding.linear_1", "off_down": 0, "off_up": 0,
                                       "rank": 4, "scale": 0.25}], 2, 16, 16, 77)
 
 
@@ -206,3 +206,80 @@ def test_conv_lora_rank_is_clamped_and_scale_uses_it():
     conv = torch.nn.Conv2d(2, 8, 3, 1, 1)
     r, dshape, ushape = L.lora_shapes(conv, 4)
     assert (r, dshape, ushape) == (2, (2, 2, 3, 3), (8, 2, 1, 1))  # min(rank, in, out): T/lora.py:104
+
+
+def test_shipped_default_configs_equal_the_references(goldens):
+    """sliders_conceptmod_amd/data/*.yaml (the CLI defaults `data/config.yaml`, `data/config-xl.yaml`) parse to the same
+    values as the reference's shipped files (recorded by make_goldens.py through the REFERENCE's config_util /
+    prompt_util), paths aside; found from any working directory."""
+    import sliders_conceptmod_amd.config_util as CU
+    import sliders_conceptmod_amd.prompt_util as PRU
+    _, man = goldens
+    for name in ("config.yaml", "config-xl.yaml"):
+        got = json.loads(CU.load_config_from_yaml(f"data/{name}").model_dump_json())
+        want = man["config_defaults"]["shipped"][name]
+        for d in (got, want):
+            d.pop("prompts_file")
+            d["pretrained_model"].pop("name_or_path")
+        assert got == want, name
+    got = [json.loads(p.model_dump_json()) for p in PRU.load_prompts_from_yaml("data/prompts.yaml")]
+    assert got == man["prompts_shipped"]
+    assert CU.load_config_from_yaml("data/config.yaml").network.type == "c3lier"  # T/data/config.yaml:7
+    xl = PRU.load_prompts_from_yaml("data/prompts-xl.yaml")
+    assert xl[0].negative == "person, very young" and xl[0].resolution == 1024
+
+
+def test_c3lier_workspace_plan_covers_every_site(libpath):
+    """Dry run of the engine with the c3lier site list of the real SD-1.x architecture: every target resolves."""
+    cfg = pcfg(OU.sd1x_config())
+    with torch.device("meta"):
+        unet = PU.UNet2DConditionModel(cfg)
+    net = L.LoRANetwork(unet, rank=4, alpha=1.0, train_method="noxattn", target_replace=C3)
+    cc = _native.make_config(cfg, torch.float16)
+    assert len(net.unet_loras) == 150 and net.flat.numel() == 2906880
+    assert _native.workspace_bytes(cc, net.engine_sites(), 8, 64, 64, 77) > 0
+
+
+# ---- VAE front end (image sliders, I/train_util.py:200-235) ------------------------------------------------------------
+def test_vae_container_matches_oracle_keys_and_fails_loudly_off_gpu():
+    from oracle import vae_ref as OV
+    import sliders_conceptmod_amd.vae as PV
+    ov = OV.AutoencoderKLRef(OV.sd_vae_config())
+    pv = PV.AutoencoderKL(PV.sd_vae_config())
+    assert list(ov.state_dict().keys()) == list(pv.state_dict().keys())
+    assert {k: tuple(v.shape) for k, v in ov.state_dict().items()} == {k: tuple(v.shape) for k, v in pv.state_dict().items()}
+    assert sum(p.numel() for p in ov.encoder.parameters()) == 34163592 and pv.config.scaling_factor == 0.18215
+    full = dict(ov.state_dict())
+    full["decoder.conv_in.weight"] = torch.zeros(1)  # a full diffusers VAE state dict: decoder entries are ignored
+    full["post_quant_conv.weight"] = torch.zeros(1)
+    pv.load_state_dict(full)
+    with pytest.raises(_native.SmiError):
+        pv.half().encode(torch.zeros(1, 3, 64, 64))
+
+
+def test_vae_image_processor_preprocess():
+    import numpy as np
+    from PIL import Image
+    from oracle import vae_ref as OV
+    from sliders_conceptmod_amd.vae import VaeImageProcessor
+    arr = np.random.default_rng(0).integers(0, 255, (64, 72, 3)).astype(np.uint8)
+    p = VaeImageProcessor(8)
+    t = p.preprocess(Image.fromarray(arr))
+    assert t.shape == (1, 3, 64, 72) and t.dtype == torch.float32
+    torch.testing.assert_close(t, OV.preprocess(torch.from_numpy(arr)), rtol=0, atol=0)
+    torch.testing.assert_close(p.preprocess(arr), t, rtol=0, atol=0)
+    assert float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+    assert p.preprocess(Image.fromarray(arr[:61, :70])).shape == (1, 3, 56, 64)  # floored to multiples of 8
+
+
+def test_vae_workspace_plan_dry_run(libpath):
+    import ctypes as C
+    c = _native.VaeConfigC()
+    c.dtype, c.in_channels, c.latent_channels, c.n_levels = 0, 3, 4, 4
+    for i, v in enumerate((128, 256, 512, 512)):
+        c.block_out_channels[i] = v
+    c.layers_per_block, c.norm_num_groups = 2, 32
+    out = C.c_size_t(0)
+    _native.check(_native.lib().smi_vae_workspace_bytes(C.byref(c), 2, 1024, 1024, C.byref(out)), "plan")
+    assert 1e9 < out.value < 40e9  # 12.9 GB: two 1024^2 images, fp32 16384^2 scores of the mid-block attention included
+    assert _native.lib().smi_vae_workspace_bytes(C.byref(c), 1, 100, 64, C.byref(out)) != 0  # not a multiple of 8
