@@ -1,13 +1,15 @@
 """Noise schedulers with the interface the reference's helpers call (conceptmod/textsliders/model_util.py:388-436
 builds them; train_util.py:103,287,324,705 and train_lora.py:157-213 use them), plus the model factory.
 
-The scheduler classes of the reference live in diffusers (absent here); these are native restatements of the two the
-slider trainers actually use -- DDIM (eta = 0) and Euler-ancestral -- with the same constants
-(beta 0.00085 -> 0.012 scaled-linear, 1000 train steps, clip_sample False, epsilon prediction).  Coefficients are
-computed on the host in fp32; the latent update runs on the GPU through `smi_sched_step` when the latents are on a
-cuda device."""
+The scheduler classes of the reference live in diffusers (absent here); these are native restatements of the four it
+can construct -- DDIM (eta = 0), Euler-ancestral, DDPM and LMS (order 4) -- with the same constants
+(beta 0.00085 -> 0.012 scaled-linear, 1000 train steps, clip_sample False) and both prediction types
+(`epsilon`, and `v_prediction` for `pretrained_model.v_pred`, model_util.py:134).  Every update is affine in
+(sample, model output, noise): the coefficients are computed on the host and the latent update runs on the GPU
+through `smi_sched_step` when the latents are on a cuda device."""
 from __future__ import annotations
 
+import os
 from typing import Literal
 
 import numpy as np
@@ -40,10 +42,17 @@ def _alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
     return torch.cumprod(1.0 - betas, dim=0)
 
 
+def _check_prediction_type(p):
+    if p not in ("epsilon", "v_prediction"):
+        raise ValueError(f"prediction_type must be epsilon or v_prediction, got {p}")
+    return p
+
+
 class DDIMScheduler:
     order = 1
 
-    def __init__(self, num_train_timesteps=1000):
+    def __init__(self, num_train_timesteps=1000, prediction_type="epsilon"):
+        self.prediction_type = _check_prediction_type(prediction_type)
         self.num_train_timesteps = num_train_timesteps
         self.alphas_cumprod = _alphas_cumprod(num_train_timesteps)
         self.final_alpha_cumprod = torch.tensor(1.0)
@@ -65,9 +74,14 @@ class DDIMScheduler:
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
         a_t = float(self.alphas_cumprod[t])
         a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else float(self.final_alpha_cumprod)
-        # prev = sqrt(a_prev) * (x - sqrt(1-a_t) eps) / sqrt(a_t) + sqrt(1 - a_prev) eps
-        cx = (a_prev / a_t) ** 0.5
-        ce = (1 - a_prev) ** 0.5 - (a_prev * (1 - a_t) / a_t) ** 0.5
+        if self.prediction_type == "epsilon":
+            # prev = sqrt(a_prev) * (x - sqrt(1-a_t) eps) / sqrt(a_t) + sqrt(1 - a_prev) eps
+            cx = (a_prev / a_t) ** 0.5
+            ce = (1 - a_prev) ** 0.5 - (a_prev * (1 - a_t) / a_t) ** 0.5
+        else:
+            # x0 = sqrt(a_t) x - sqrt(1-a_t) v ; eps = sqrt(a_t) v + sqrt(1-a_t) x ; prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+            cx = (a_prev * a_t) ** 0.5 + ((1 - a_prev) * (1 - a_t)) ** 0.5
+            ce = ((1 - a_prev) * a_t) ** 0.5 - (a_prev * (1 - a_t)) ** 0.5
         return _StepOutput(_affine(sample, model_output, None, cx, ce, 0.0))
 
     def add_noise(self, original, noise, timesteps):
@@ -79,10 +93,38 @@ class DDIMScheduler:
         return sa * original + sb * noise
 
 
+class DDPMScheduler(DDIMScheduler):
+    """Ancestral sampling with the "fixed_small" posterior variance (diffusers' default), leading timestep spacing."""
+
+    def step(self, model_output, timestep, sample, generator=None):
+        t = int(timestep)
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cur_a = a_t / a_prev
+        cur_b = 1 - cur_a
+        c0 = a_prev ** 0.5 * cur_b / b_t  # weight of the predicted x0
+        c1 = cur_a ** 0.5 * b_prev / b_t  # weight of the current sample
+        if self.prediction_type == "epsilon":  # x0 = (x - sqrt(b_t) eps) / sqrt(a_t)
+            cx, ce = c1 + c0 / a_t ** 0.5, -c0 * (b_t / a_t) ** 0.5
+        else:                                  # x0 = sqrt(a_t) x - sqrt(b_t) v
+            cx, ce = c1 + c0 * a_t ** 0.5, -c0 * b_t ** 0.5
+        noise, cn = None, 0.0
+        if t > 0:
+            rank, world = getattr(self, "dp_shard", (0, 1))
+            from .parallel import shard_noise
+            noise = shard_noise(lambda shp: torch.randn(shp, dtype=torch.float32, generator=generator),
+                                tuple(model_output.shape), rank, world)
+            cn = max(b_prev / b_t * cur_b, 1e-20) ** 0.5
+        return _StepOutput(_affine(sample, model_output, noise, cx, ce, cn))
+
+
 class EulerAncestralDiscreteScheduler:
     order = 1
 
-    def __init__(self, num_train_timesteps=1000):
+    def __init__(self, num_train_timesteps=1000, prediction_type="epsilon"):
+        self.prediction_type = _check_prediction_type(prediction_type)
         self.num_train_timesteps = num_train_timesteps
         ac = _alphas_cumprod(num_train_timesteps)
         self._train_sigmas = (((1 - ac) / ac) ** 0.5).numpy().astype(np.float64)
@@ -121,24 +163,77 @@ class EulerAncestralDiscreteScheduler:
         from .parallel import shard_noise
         noise = shard_noise(lambda shp: torch.randn(shp, dtype=torch.float32, generator=generator),
                             tuple(model_output.shape), rank, world)
-        # prev = x + eps * (sigma_down - sigma) + noise * sigma_up       (derivative = eps for epsilon prediction)
-        return _StepOutput(_affine(sample, model_output, noise, 1.0, sigma_down - sigma, sigma_up))
+        dt = sigma_down - sigma
+        if self.prediction_type == "epsilon":
+            # prev = x + eps * dt + noise * sigma_up       (derivative = eps for epsilon prediction)
+            cx, ce = 1.0, dt
+        else:
+            # x0 = -sigma v / sqrt(sigma^2+1) + x / (sigma^2+1); derivative = (x - x0) / sigma
+            cx, ce = 1.0 + dt * sigma / (sigma ** 2 + 1), dt / (sigma ** 2 + 1) ** 0.5
+        return _StepOutput(_affine(sample, model_output, noise, cx, ce, sigma_up))
 
     def add_noise(self, original, noise, timesteps):
         i = self._index(torch.as_tensor(timesteps).reshape(-1)[0])
         return original + noise * float(self.sigmas[i])
 
 
+class LMSDiscreteScheduler(EulerAncestralDiscreteScheduler):
+    """Linear multistep (order 4, Katherine Crowson's k-diffusion `sample_lms`) on the same sigma ladder as Euler-a:
+    prev = x + sum_j c_j d_{i-j}, d = (x - x0) / sigma, c_j = integral over [sigma_i, sigma_{i+1}] of the j-th Lagrange
+    basis polynomial through the last `order` sigmas.  Stateful: the derivative history restarts at set_timesteps."""
+    order = 4
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        super().set_timesteps(num_inference_steps, device)
+        self.derivatives = []
+
+    def get_lms_coefficient(self, order, t, current_order):
+        from scipy import integrate
+        sig = self.sigmas.double().numpy()
+
+        def basis(tau):
+            prod = 1.0
+            for k in range(order):
+                if current_order == k:
+                    continue
+                prod *= (tau - sig[t - k]) / (sig[t - current_order] - sig[t - k])
+            return prod
+
+        return integrate.quad(basis, sig[t], sig[t + 1], epsrel=1e-4)[0]
+
+    def step(self, model_output, timestep, sample, order: int = 4, generator=None):
+        i = self._index(timestep)
+        sigma = float(self.sigmas[i])
+        # derivative d = (x - x0) / sigma as an affine map of (x, model output)
+        if self.prediction_type == "epsilon":
+            dx, de = 0.0, 1.0
+        else:
+            dx, de = sigma / (sigma ** 2 + 1), 1.0 / (sigma ** 2 + 1) ** 0.5
+        d = dx * sample.float() + de * model_output.float()
+        hist = getattr(self, "derivatives", [])
+        hist.append(d)
+        if len(hist) > order:
+            hist.pop(0)
+        self.derivatives = hist
+        order = min(i + 1, order, len(hist))
+        coeffs = [self.get_lms_coefficient(order, i, j) for j in range(order)]
+        prev = sample.float()
+        for c, dj in zip(coeffs, reversed(hist)):
+            prev = prev + float(c) * dj
+        return _StepOutput(prev)
+
+
 def create_noise_scheduler(scheduler_name: AVAILABLE_SCHEDULERS = "ddpm", prediction_type="epsilon"):
+    """model_util.py:388-436: the four schedulers with the reference's constants; unknown names raise ValueError."""
     name = scheduler_name.lower().replace(" ", "_")
-    if prediction_type != "epsilon":
-        raise ValueError("only epsilon prediction is built (v_pred models: SD-2.x are outside this tier)")
     if name == "ddim":
-        return DDIMScheduler()
+        return DDIMScheduler(prediction_type=prediction_type)
+    if name == "ddpm":
+        return DDPMScheduler(prediction_type=prediction_type)
+    if name == "lms":
+        return LMSDiscreteScheduler(prediction_type=prediction_type)
     if name == "euler_a":
-        return EulerAncestralDiscreteScheduler()
-    if name in ("ddpm", "lms"):
-        raise ValueError(f"scheduler '{name}' is not built natively; the slider configs use ddim / euler_a")
+        return EulerAncestralDiscreteScheduler(prediction_type=prediction_type)
     raise ValueError(f"Unknown scheduler name: {name}")
 
 
@@ -226,9 +321,10 @@ def load_models(pretrained_model_name_or_path: str, scheduler_name: str = "ddim"
     :359-385).  `synthetic://sd1x|sdxl|tiny_sd1x|tiny_sdxl` builds the architecture with seeded random weights (no
     network here).  A local diffusers directory is loaded with safetensors; its text encoders through `transformers`."""
     from . import unet as PU
-    if v2 or v_pred:
-        raise ValueError("SD-2.x / v-prediction models are outside this tier (epsilon-prediction SD-1.x / SD-XL only)")
-    scheduler = create_noise_scheduler(scheduler_name)
+    if v2 and not os.path.isdir(pretrained_model_name_or_path):
+        raise ValueError("SD-2.x needs a local diffusers directory (its UNet config is read from it)")
+    # model_util.py:134: prediction_type = "v_prediction" if v_pred else "epsilon"
+    scheduler = create_noise_scheduler(scheduler_name, prediction_type="v_prediction" if v_pred else "epsilon")
     name = pretrained_model_name_or_path
     if name.startswith("synthetic://"):
         kind = name[len("synthetic://"):]
@@ -248,7 +344,6 @@ def load_models(pretrained_model_name_or_path: str, scheduler_name: str = "ddim"
             pooled = cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim
         enc = SyntheticTextEncoder(cfg.cross_attention_dim, pooled)
         return None, enc, unet, scheduler
-    import os
     if os.path.isdir(name):
         unet = _unet_from_dir(name, weight_dtype)
         from transformers import CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer

@@ -375,3 +375,44 @@ def test_cli_main_runs_the_shipped_c3lier_config_end_to_end(tmp_path, monkeypatc
     conv_up = [v for k, v in sd.items() if "conv1.lora_up" in k]
     assert conv_up and all(v.ndim == 4 and v.dtype == torch.float16 for v in conv_up)
     assert any(float(v.float().abs().max()) > 0 for v in conv_up), "conv adaptors did not train"
+
+
+@pytest.mark.parametrize("sched_name,model", [("euler_a", "tiny_sdxl"), ("ddim", "tiny_sd1x")])
+def test_native_preroll_matches_the_oracle(sched_name, model):
+    """Row f-1: the on-device pre-roll (SliderStep.preroll: engine forward, smi_cfg_combine, smi_sched_step per denoising
+    step, adaptor ON, CFG scale 3) against the ORACLE's diffusion(_xl) (T/train_util.py:306-327, 677-708) on the CPU --
+    an independent implementation, not the same engine.  Euler-ancestral noise is drawn on the host from the same seed
+    on both sides."""
+    import sliders_conceptmod_amd.model_util as MU
+    from sliders_conceptmod_amd.step import SliderStep
+    from oracle import sched_ref as S, slider_ref as R
+    from test_engine_gpu import build_pair
+    xl = model.endswith("xl")
+    ocfg, ou, onet, pu, pnet = build_pair(model, torch.float16)
+    g = torch.Generator().manual_seed(4)
+    keys = ["target", "positive", "neutral", "unconditional"]
+    emb = {k: torch.randn(1, 77, ocfg.cross_attention_dim, generator=g) for k in keys}
+    pooled = tid = None
+    if xl:
+        pdim = ocfg.projection_class_embeddings_input_dim - 6 * ocfg.addition_time_embed_dim
+        pooled = {k: torch.randn(1, pdim, generator=g) for k in keys}
+        tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]])
+    lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(3))
+    osch, psch = S.create_noise_scheduler_ref(sched_name), MU.create_noise_scheduler(sched_name)
+    osch.set_timesteps(12), psch.set_timesteps(12)
+    lat0 = lat * float(psch.init_noise_sigma)
+    te = R.concat_embeddings(emb["unconditional"], emb["target"], 2)
+    torch.manual_seed(11)
+    with torch.no_grad(), onet:
+        if xl:
+            ref = R.diffusion_xl(ou, osch, lat0, te, R.concat_embeddings(pooled["unconditional"], pooled["target"], 2),
+                                 R.concat_embeddings(tid, tid, 2), guidance_scale=3.0, total_timesteps=5)
+        else:
+            ref = R.diffusion(ou, osch, lat0, te, total_timesteps=5, guidance_scale=3.0)
+    step = SliderStep(pu, pnet, psch)
+    cond = step.make_conditioning(emb, 2, pooled, tid)
+    torch.manual_seed(11)
+    got = step.preroll(lat0.cuda(), cond, 5, 3.0)
+    e = float((got.cpu() - ref).norm() / ref.norm())
+    print(f"{model} {sched_name}: 5-step pre-roll vs oracle rel err {e:.2e}")
+    assert e < 3e-3, e
