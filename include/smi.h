@@ -83,6 +83,20 @@ typedef struct smi_vae_config {
   int norm_num_groups;  /* 32 */
 } smi_vae_config;
 
+/* Architecture of a transformers CLIPTextModel / CLIPTextModelWithProjection (the prompt front end:
+ * conceptmod/textsliders/train_util.py:108-155 `text_encode`, `text_encode_xl`). */
+typedef struct smi_clip_config {
+  int dtype;
+  int vocab_size;        /* 49408 */
+  int hidden_size;       /* 768 (CLIP ViT-L/14 text) / 1280 (OpenCLIP bigG) */
+  int num_layers;        /* 12 / 32 */
+  int num_heads;         /* 12 / 20 */
+  int intermediate_size; /* 3072 / 5120 */
+  int max_positions;     /* 77 */
+  int hidden_act;        /* 0 quick_gelu, 1 gelu */
+  int projection_dim;    /* 0: none (CLIPTextModel); > 0: text_projection (CLIPTextModelWithProjection) */
+} smi_clip_config;
+
 typedef struct smi_engine smi_engine;
 
 const char* smi_last_error(void);
@@ -133,6 +147,22 @@ int smi_vae_workspace_bytes(const smi_vae_config* cfg, int batch, int h, int w, 
 int smi_vae_create(const smi_vae_config* cfg, const smi_weight* weights, int n_weights, int batch, int h, int w,
                    void* workspace, size_t workspace_bytes, void* stream, smi_engine** out);
 int smi_vae_encode(smi_engine* e, int n, const float* image, float* moments_out);
+
+/* ---- CLIP text encoder (prompt front end) -----------------------------------------------------------------------------
+ * Replaces `text_encoder(tokens)[0]` (train_util.py:119-120) and `text_encoder(tokens, output_hidden_states=True)`
+ * -> `[0]`, `.hidden_states[-2]` (train_util.py:139-144).  Causal self-attention, pre-LayerNorm blocks.
+ *   weights: the transformers state_dict (`text_model.embeddings.token_embedding.weight`, ...,
+ *            `text_model.final_layer_norm.*`, `text_projection.weight` when projection_dim > 0), dtype T
+ *   ids         int32 [n, max_positions]   token ids (host tokenizer output)
+ *   eos_pos     int32 [n]                  position of the pooled token (transformers: the EOS token)
+ *   last_hidden T [n, L, hidden]  final_layer_norm(output of the last layer)            (may be NULL)
+ *   penultimate T [n, L, hidden]  output of layer num_layers-1, no final norm = hidden_states[-2]   (may be NULL)
+ *   pooled      T [n, projection_dim or hidden]  last_hidden[eos_pos] (x text_projection)           (may be NULL) */
+int smi_clip_workspace_bytes(const smi_clip_config* cfg, int batch, size_t* bytes);
+int smi_clip_create(const smi_clip_config* cfg, const smi_weight* weights, int n_weights, int batch, void* workspace,
+                    size_t workspace_bytes, void* stream, smi_engine** out);
+int smi_clip_encode(smi_engine* e, int n, const int32_t* ids, const int32_t* eos_pos, void* last_hidden,
+                    void* penultimate, void* pooled);
 
 /* eps = unet(sample, t, ctx[, text_embeds, time_ids]).sample           (train_util.py:290-294, 471-476)
  *   sample      f32 [n, 4, h, w]  (NCHW, already scale_model_input-ed)

@@ -37,6 +37,12 @@ class VaeConfigC(C.Structure):
                 ("norm_num_groups", C.c_int)]
 
 
+class ClipConfigC(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("vocab_size", C.c_int), ("hidden_size", C.c_int), ("num_layers", C.c_int),
+                ("num_heads", C.c_int), ("intermediate_size", C.c_int), ("max_positions", C.c_int),
+                ("hidden_act", C.c_int), ("projection_dim", C.c_int)]
+
+
 class WeightC(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
 
@@ -67,6 +73,10 @@ _SIGS = {
     "smi_vae_create": (C.c_int, [C.POINTER(VaeConfigC), C.POINTER(WeightC), C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "smi_vae_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "smi_clip_workspace_bytes": (C.c_int, [C.POINTER(ClipConfigC), C.c_int, C.POINTER(C.c_size_t)]),
+    "smi_clip_create": (C.c_int, [C.POINTER(ClipConfigC), C.POINTER(WeightC), C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                  C.c_void_p, C.POINTER(C.c_void_p)]),
+    "smi_clip_encode": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
     "smi_unet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "smi_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -347,6 +357,57 @@ class VaeEngine:
                           device=image.device)
         check(lib().smi_vae_encode(self.handle, n, ptr(image), ptr(out)), "smi_vae_encode")
         return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().smi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ClipEngine:
+    """CLIP text encoder on the HIP engine (smi_clip_*): token ids -> last hidden state, hidden_states[-2], pooled."""
+
+    ACT = {"quick_gelu": 0, "gelu": 1}
+
+    def __init__(self, cfg, dtype: torch.dtype, state: dict, batch: int, device):
+        c = ClipConfigC()
+        c.dtype = DTYPE_CODE[dtype]
+        c.vocab_size, c.hidden_size, c.num_layers = cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers
+        c.num_heads, c.intermediate_size = cfg.num_attention_heads, cfg.intermediate_size
+        c.max_positions = cfg.max_position_embeddings
+        if cfg.hidden_act not in self.ACT:
+            raise SmiError(f"CLIP hidden_act '{cfg.hidden_act}' is not built (quick_gelu / gelu)")
+        c.hidden_act = self.ACT[cfg.hidden_act]
+        c.projection_dim = cfg.projection_dim or 0
+        self.cfg_c, self.batch, self.dtype = c, batch, dtype
+        out = C.c_size_t(0)
+        check(lib().smi_clip_workspace_bytes(C.byref(c), batch, C.byref(out)), "smi_clip_workspace_bytes")
+        self.workspace = torch.empty(out.value, dtype=torch.uint8, device=device)
+        warr, self._keep = _weight_table(state, dtype, self.workspace.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.workspace.device):
+            check(lib().smi_clip_create(C.byref(c), warr, len(state), batch, ptr(self.workspace), out.value, stream_ptr(),
+                                        C.byref(handle)), "smi_clip_create")
+        self.handle = handle
+
+    def encode(self, ids: torch.Tensor, eos_pos: torch.Tensor):
+        n, L = ids.shape
+        dev = self.workspace.device
+        d = self.cfg_c.hidden_size
+        last = torch.empty((n, L, d), dtype=self.dtype, device=dev)
+        pen = torch.empty((n, L, d), dtype=self.dtype, device=dev)
+        pooled = torch.empty((n, self.cfg_c.projection_dim or d), dtype=self.dtype, device=dev)
+        ids = ids.to(dev, torch.int32).contiguous()
+        eos = eos_pos.to(dev, torch.int32).contiguous()
+        check(lib().smi_clip_encode(self.handle, n, ptr(ids), ptr(eos), ptr(last), ptr(pen), ptr(pooled)),
+              "smi_clip_encode")
+        return last, pen, pooled
 
     def close(self):
         if getattr(self, "handle", None):

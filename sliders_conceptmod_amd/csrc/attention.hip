@@ -181,13 +181,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         }
       }
     }
-    // mask keys beyond Nk (ragged last tile only), tile max
-    if (k0 + TK > p.Nk) {
+    // mask keys beyond Nk (ragged last tile only) and, for causal attention, keys after the query; tile max
+    if (k0 + TK > p.Nk || p.causal) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (k0 + sub * 32 + acc_row(r, h2) >= p.Nk) st[sub][r] = -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + sub * 32 + acc_row(r, h2);
+          if (key >= p.Nk || (p.causal && key > q_idx)) st[sub][r] = -INFINITY;
+        }
     }
     float mloc = -INFINITY;
 #pragma unroll

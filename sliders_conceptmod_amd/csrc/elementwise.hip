@@ -51,7 +51,7 @@ __global__ void geglu_bwd_kernel(const T* __restrict__ proj, const T* __restrict
   }
 }
 
-template <typename T, int OP>  // 0: silu(a)   1: a + b
+template <typename T, int OP>  // 0: silu(a)   1: a + b   2: quick_gelu(a) = a * sigmoid(1.702 a)   3: gelu(a) (erf)
 __global__ void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n8) {
   GSTRIDE(i, n8) {
     Pack8<T> x, z, o;
@@ -60,7 +60,8 @@ __global__ void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* _
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float v = to_f(x.e[e]);
-      o.e[e] = from_f<T>(OP == 0 ? silu_f(v) : v + to_f(z.e[e]));
+      o.e[e] = from_f<T>(OP == 0 ? silu_f(v) : OP == 1 ? v + to_f(z.e[e]) : OP == 2 ? v / (1.f + __expf(-1.702f * v))
+                                                                                      : gelu_f(v));
     }
     *reinterpret_cast<u32x4*>(y + i * 8) = o.u;
   }
@@ -164,6 +165,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, T*
   if (w == 0 && c < C) {
     const int l = threadIdx.x & 63;
     out[(int64_t)n * C + c] = from_f<T>(((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * mul);
+  }
+}
+// CLIP text embeddings: out[n*L + l][:] = tok[ids[n*L + l]][:] + pos[l][:]
+template <typename T>
+__global__ void embed_kernel(const int* __restrict__ ids, const T* __restrict__ tok, const T* __restrict__ pos,
+                             T* __restrict__ out, int64_t rows, int L, int d8, int vocab) {
+  GSTRIDE(i, rows * d8) {
+    const int c = (int)(i % d8);
+    const int64_t r = i / d8;
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    Pack8<T> a, b, o;
+    a.u = *reinterpret_cast<const u32x4*>(tok + ((int64_t)id * d8 + c) * 8);
+    b.u = *reinterpret_cast<const u32x4*>(pos + ((int64_t)(r % L) * d8 + c) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(to_f(a.e[e]) + to_f(b.e[e]));
+    *reinterpret_cast<u32x4*>(out + i * 8) = o.u;
+  }
+}
+// out[n][:] = src[n * L + idx[n]][:]
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, const int* __restrict__ idx, T* __restrict__ out, int n,
+                                   int L, int d8) {
+  GSTRIDE(i, (int64_t)n * d8) {
+    const int c = (int)(i % d8);
+    const int64_t r = i / d8;
+    int j = idx[r];
+    j = j < 0 ? 0 : (j >= L ? L - 1 : j);
+    *reinterpret_cast<u32x4*>(out + i * 8) = *reinterpret_cast<const u32x4*>(src + ((r * L + j) * d8 + c) * 8);
   }
 }
 // one workgroup per row: max, sum of exp, normalised write (three passes over a row that sits in L2)
@@ -349,6 +379,40 @@ int launch_silu(int dtype, const void* x, void* y, int64_t n, hipStream_t stream
     hipLaunchKernelGGL((ew_kernel<f16, 0>), dim3(grid), dim3(256), 0, stream, (const f16*)x, nullptr, (f16*)y, n / 8);
   else
     hipLaunchKernelGGL((ew_kernel<bf16, 0>), dim3(grid), dim3(256), 0, stream, (const bf16*)x, nullptr, (bf16*)y, n / 8);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_act(int dtype, const void* x, void* y, int64_t n, int kind, hipStream_t stream) {
+  SMI_CHECK(n % 8 == 0 && (kind == 0 || kind == 1), "act: n %% 8, kind 0 (quick_gelu) or 1 (gelu)");
+  const int grid = ew_grid(n / 8);
+#define L(TT_, OP_) hipLaunchKernelGGL((ew_kernel<TT_, OP_>), dim3(grid), dim3(256), 0, stream, (const TT_*)x, nullptr, (TT_*)y, n / 8)
+  if (dtype == DT_F16) {
+    if (kind == 0) L(f16, 2); else L(f16, 3);
+  } else {
+    if (kind == 0) L(bf16, 2); else L(bf16, 3);
+  }
+#undef L
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_embed(int dtype, const int* ids, const void* tok, const void* pos, void* out, int64_t rows, int L, int d,
+                 int vocab, hipStream_t stream) {
+  SMI_CHECK(d % 8 == 0, "embed: d %% 8");
+  const int grid = ew_grid(rows * (d / 8));
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(embed_kernel<f16>, dim3(grid), dim3(256), 0, stream, ids, (const f16*)tok, (const f16*)pos, (f16*)out, rows, L, d / 8, vocab);
+  else
+    hipLaunchKernelGGL(embed_kernel<bf16>, dim3(grid), dim3(256), 0, stream, ids, (const bf16*)tok, (const bf16*)pos, (bf16*)out, rows, L, d / 8, vocab);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_gather_rows(int dtype, const void* src, const int* idx, void* out, int n, int L, int d, hipStream_t stream) {
+  SMI_CHECK(d % 8 == 0, "gather_rows: d %% 8");
+  const int grid = ew_grid((int64_t)n * (d / 8));
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(gather_rows_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, idx, (f16*)out, n, L, d / 8);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, idx, (bf16*)out, n, L, d / 8);
   SMI_HIP(hipGetLastError());
   return 0;
 }

@@ -1105,6 +1105,7 @@ struct smi_engine {
     p.Nk = Nk;
     p.D = C / heads;
     p.scale = 1.f / sqrtf((float)p.D);
+    p.causal = attn_causal ? 1 : 0;
     if (qkv) {
       p.Q = qkv->p;
       p.K = (char*)qkv->p + (size_t)C * esz();
@@ -1600,6 +1601,96 @@ struct smi_engine {
   }
 
   // ---------------------------------------------------------------------------------------------------------
+  // CLIP text encoder (transformers CLIPTextModel[WithProjection]; T/train_util.py:108-155), forward only: token +
+  // position embedding, pre-LayerNorm blocks with CAUSAL self-attention (the fused attention kernel with its causal
+  // mask), quick_gelu / gelu MLP, final LayerNorm, pooled EOS row (x text_projection).
+  // ---------------------------------------------------------------------------------------------------------
+  bool attn_causal = false;
+  bool is_clip = false;
+  smi_clip_config ccfg{};
+  struct CLayer {
+    Norm n1, n2;
+    Lin qkv, out, fc1, fc2;
+  };
+  std::vector<CLayer> c_layers;
+  Norm c_final;
+  Lin c_proj;
+  const void* c_tok = nullptr;
+  const void* c_pos = nullptr;
+
+  void build_clip() {
+    const int d = ccfg.hidden_size;
+    c_tok = Wd("text_model.embeddings.token_embedding.weight");
+    c_pos = Wd("text_model.embeddings.position_embedding.weight");
+    check_shape("text_model.embeddings.token_embedding.weight", {ccfg.vocab_size, d});
+    check_shape("text_model.embeddings.position_embedding.weight", {ccfg.max_positions, d});
+    c_layers.resize(ccfg.num_layers);
+    for (int i = 0; i < ccfg.num_layers; ++i) {
+      const std::string b = "text_model.encoder.layers." + std::to_string(i);
+      CLayer& L = c_layers[i];
+      L.n1 = make_norm(b + ".layer_norm1", d, 1e-5f);
+      L.qkv = make_fused(b + ".self_attn", {"q_proj", "k_proj", "v_proj"}, d, d, false);
+      char* bq = (char*)pack_alloc((size_t)3 * d * esz());
+      const char* parts[3] = {"q_proj", "k_proj", "v_proj"};
+      for (int j = 0; j < 3; ++j) {
+        const void* src = Wd(b + ".self_attn." + parts[j] + ".bias");
+        if (!dry && !err && src)
+          (void)hipMemcpyAsync(bq + (size_t)j * d * esz(), src, (size_t)d * esz(), hipMemcpyDeviceToDevice, stream);
+      }
+      L.qkv.b = bq;
+      L.out = make_lin(b + ".self_attn.out_proj", d, d, true, false);
+      L.n2 = make_norm(b + ".layer_norm2", d, 1e-5f);
+      L.fc1 = make_lin(b + ".mlp.fc1", d, ccfg.intermediate_size, true, false);
+      L.fc2 = make_lin(b + ".mlp.fc2", ccfg.intermediate_size, d, true, false);
+    }
+    c_final = make_norm("text_model.final_layer_norm", d, 1e-5f);
+    if (ccfg.projection_dim > 0) c_proj = make_lin("text_projection", d, ccfg.projection_dim, false, false);
+    gscale = (float*)pack_alloc(256 * sizeof(float));
+    finish_lora();
+  }
+
+  int forward_clip(int n, const int* ids, const int* eos_pos, void* last_hidden, void* penultimate, void* pooled) {
+    n_ad = 0;
+    cur = &arena[0];
+    cur->reset();
+    tens = &tens_[0];
+    tens->clear();
+    saving = false;
+    lora_down = lora_up = nullptr;
+    mult = 0.f;
+    attn_causal = true;
+    const int L = ccfg.max_positions, d = ccfg.hidden_size;
+    Ten* h = new_ten((int64_t)n * L, d, n, L, 1);
+    RUN(launch_embed(dtype, ids, c_tok, c_pos, h->p, (int64_t)n * L, L, d, ccfg.vocab_size, stream));
+    for (int i = 0; i < ccfg.num_layers; ++i) {
+      const CLayer& ly = c_layers[i];
+      if (i == ccfg.num_layers - 1 && penultimate)  // hidden_states[-2]: what enters the last layer
+        RUN(launch_copy_cols(dtype, h->p, d, penultimate, d, 0, (int)h->rows, d, stream));
+      Ten* qkv = linear(layernorm(h, ly.n1), ly.qkv);
+      Ten* o = attention(qkv, nullptr, nullptr, ccfg.num_heads, d, n, L, L);
+      h = linear(o, ly.out, h);
+      Ten* f = linear(layernorm(h, ly.n2), ly.fc1);
+      Ten* a = new_ten(f->rows, f->cols, n, L, 1);
+      RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_act(dtype, f->p, a->p, f->rows * f->cols, ccfg.hidden_act, stream));
+      h = linear(a, ly.fc2, h);
+    }
+    attn_causal = false;
+    Ten* fin = layernorm(h, c_final);
+    if (last_hidden) RUN(launch_copy_cols(dtype, fin->p, d, last_hidden, d, 0, (int)fin->rows, d, stream));
+    if (pooled) {
+      Ten* pl = new_ten(n, d, n, 1, 1);
+      RUN(launch_gather_rows(dtype, fin->p, eos_pos, pl->p, n, L, d, stream));
+      if (ccfg.projection_dim > 0) pl = linear(pl, c_proj);
+      RUN(launch_copy_cols(dtype, pl->p, pl->cols, pooled, pl->cols, 0, n, pl->cols, stream));
+    }
+    if (cur->overflow && !dry) {
+      set_error("workspace too small for this call (needs %zu bytes, has %zu)", cur->peak, cur->cap);
+      return -3;
+    }
+    return err ? -1 : 0;
+  }
+
+  // ---------------------------------------------------------------------------------------------------------
   // whole passes
   // ---------------------------------------------------------------------------------------------------------
   int forward(int n, int n_adapted, const float* sample, float timestep, const void* ctxp, const void* text_embeds,
@@ -2033,6 +2124,84 @@ int smi_vae_encode(smi_engine* e, int n, const float* image, float* moments_out)
   return e->forward_vae(n, image, moments_out);
 }
 
+// ---- CLIP text encoder engine ------------------------------------------------------------------------------------------
+static int check_clip_cfg(const smi_clip_config* c, int batch) {
+  SMI_CHECK(c != nullptr, "config is NULL");
+  SMI_CHECK(c->dtype == SMI_DTYPE_F16 || c->dtype == SMI_DTYPE_BF16, "dtype must be f16 (0) or bf16 (1)");
+  SMI_CHECK(c->hidden_size % 64 == 0 && c->hidden_size <= 2048 && c->num_heads > 0 && c->hidden_size % c->num_heads == 0 &&
+                (c->hidden_size / c->num_heads) % 8 == 0 && c->intermediate_size % 64 == 0 && c->num_layers >= 1 &&
+                c->vocab_size > 0 && c->max_positions > 0 && (c->hidden_act == 0 || c->hidden_act == 1) &&
+                c->projection_dim >= 0 && c->projection_dim % 8 == 0 && batch > 0,
+            "CLIP config out of range (hidden %% 64, hidden <= 2048, head_dim %% 8, intermediate %% 64)");
+  return 0;
+}
+static void clip_setup(smi_engine* e, const smi_clip_config* cfg, const smi_weight* weights, int n_weights, int batch) {
+  e->is_clip = true;
+  e->ccfg = *cfg;
+  e->dtype = cfg->dtype;
+  e->max_n = batch;
+  for (int i = 0; i < n_weights; ++i) e->wmap[weights[i].name] = &weights[i];
+}
+static int clip_plan(const smi_clip_config* cfg, int batch, size_t out[2]) {
+  smi_engine e;
+  e.dry = true;
+  clip_setup(&e, cfg, nullptr, 0, batch);
+  e.build_clip();
+  if (e.err) return -1;
+  out[0] = align_up(e.wpack.peak, 4096);
+  e.forward_clip(batch, nullptr, nullptr, (void*)16, (void*)16, (void*)16);
+  out[1] = align_up(e.arena[0].peak, 4096);
+  return e.err ? -1 : 0;
+}
+
+int smi_clip_workspace_bytes(const smi_clip_config* cfg, int batch, size_t* bytes) {
+  if (check_clip_cfg(cfg, batch)) return -1;
+  SMI_CHECK(bytes != nullptr, "bad arguments");
+  size_t r[2];
+  if (clip_plan(cfg, batch, r)) return -1;
+  *bytes = r[0] + r[1] + 2 * 4096;
+  return 0;
+}
+
+int smi_clip_create(const smi_clip_config* cfg, const smi_weight* weights, int n_weights, int batch, void* workspace,
+                    size_t workspace_bytes, void* stream, smi_engine** out) {
+  if (check_clip_cfg(cfg, batch)) return -1;
+  SMI_CHECK(out && workspace && weights && n_weights > 0, "bad arguments");
+  size_t r[2];
+  if (clip_plan(cfg, batch, r)) return -1;
+  SMI_CHECK(r[0] + r[1] + 2 * 4096 <= workspace_bytes, "workspace too small: need %zu bytes, got %zu",
+            r[0] + r[1] + 2 * 4096, workspace_bytes);
+  smi_engine* e = new smi_engine();
+  e->stream = (hipStream_t)stream;
+  clip_setup(e, cfg, weights, n_weights, batch);
+  char* base = (char*)align_up((size_t)workspace, 4096);
+  e->ws = (char*)workspace;
+  e->ws_bytes = workspace_bytes;
+  e->wpack.base = base;
+  e->wpack.cap = r[0];
+  e->arena[0].base = base + r[0];
+  e->arena[0].cap = r[1];
+  e->build_clip();
+  if (!e->err) (void)hipStreamSynchronize(e->stream);
+  if (e->err || hipGetLastError() != hipSuccess) {
+    if (!e->err) set_error("HIP error while packing the CLIP weights");
+    delete e;
+    return -1;
+  }
+  e->wmap.clear();
+  *out = e;
+  return 0;
+}
+
+int smi_clip_encode(smi_engine* e, int n, const int32_t* ids, const int32_t* eos_pos, void* last_hidden,
+                    void* penultimate, void* pooled) {
+  SMI_CHECK(e && e->is_clip && ids, "smi_clip_encode: NULL argument or not a CLIP engine");
+  SMI_CHECK(n >= 1 && n <= e->max_n, "batch %d outside [1, %d] the engine was created for", n, e->max_n);
+  SMI_CHECK(!pooled || eos_pos, "pooled output needs eos_pos");
+  e->err = false;
+  return e->forward_clip(n, ids, eos_pos, last_hidden, penultimate, pooled);
+}
+
 int smi_weights_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, size_t* bytes) {
   if (check_cfg(cfg)) return -1;
   SMI_CHECK(bytes != nullptr, "bad arguments");
@@ -2057,7 +2226,7 @@ int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ct
                size_t arena_bytes) {
   SMI_CHECK(e && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
             "bad arguments");
-  SMI_CHECK(!e->is_vae, "smi_replan: VAE engines are created per image size");
+  SMI_CHECK(!e->is_vae && !e->is_clip, "smi_replan: only UNet engines re-plan");
   size_t r[3];
   if (plan(&e->cfg, e->sites.data(), (int)e->sites.size(), batch, batch_adapted, h, w, ctx_len, r)) return -1;
   char* base = arena ? (char*)align_up((size_t)arena, 4096) : e->arena_home;
@@ -2098,7 +2267,7 @@ int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* s
                              const void* text_embeds, const float* time_ids, const float* lora_down_flat,
                              const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out) {
   SMI_CHECK(e && sample && ctx && eps_out, "NULL argument");
-  SMI_CHECK(!e->is_vae, "this engine is a VAE encoder (use smi_vae_encode)");
+  SMI_CHECK(!e->is_vae && !e->is_clip, "this engine is a VAE / CLIP encoder (use smi_vae_encode / smi_clip_encode)");
   SMI_CHECK(n >= 1 && n <= e->max_n, "batch %d outside [1, %d] the engine was created for", n, e->max_n);
   SMI_CHECK(n_adapted >= 0 && n_adapted <= n && n_adapted <= e->max_n_ad,
             "adapted batch %d outside [0, min(%d, %d)]", n_adapted, n, e->max_n_ad);
@@ -2120,7 +2289,7 @@ int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, 
 
 int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat, float* d_lora_up_flat) {
   SMI_CHECK(e && d_eps && d_lora_down_flat && d_lora_up_flat, "NULL argument");
-  SMI_CHECK(!e->is_vae, "this engine is a VAE encoder: it has no backward");
+  SMI_CHECK(!e->is_vae && !e->is_clip, "this engine is a VAE / CLIP encoder: it has no backward");
   e->err = false;
   return e->backward(d_eps, d_lora_down_flat, d_lora_up_flat);
 }

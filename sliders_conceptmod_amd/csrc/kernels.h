@@ -73,6 +73,7 @@ struct AttnParams {
   int64_t ldq = 0, ldk = 0, ldv = 0, ldo = 0;
   int B = 0, H = 0, Nq = 0, Nk = 0, D = 0;
   float scale = 1.f;
+  int causal = 0;  // forward only: key j is visible to query i iff j <= i (CLIP text encoder)
   // backward
   const void* dO = nullptr;
   int64_t lddo = 0;
@@ -112,6 +113,11 @@ int launch_geglu_fwd(int dtype, const void* proj, void* out, int M, int C4, hipS
 int launch_geglu_bwd(int dtype, const void* proj, const void* dout, void* dproj, int M, int C4, hipStream_t stream);
 int launch_silu(int dtype, const void* x, void* y, int64_t n, hipStream_t stream);
 int launch_add(int dtype, const void* a, const void* b, void* y, int64_t n, hipStream_t stream);  // y = a + b
+// CLIP text encoder pieces: y = quick_gelu(x) (kind 0) / gelu(x) (kind 1); token + position embedding lookup; row gather
+int launch_act(int dtype, const void* x, void* y, int64_t n, int kind, hipStream_t stream);
+int launch_embed(int dtype, const int* ids, const void* tok, const void* pos, void* out, int64_t rows, int L, int d,
+                 int vocab, hipStream_t stream);
+int launch_gather_rows(int dtype, const void* src, const int* idx, void* out, int n, int L, int d, hipStream_t stream);
 // copy [M, C] (src row stride lds) into dst columns [col0, col0+C) of a [M, ldd] tensor (concat / split)
 int launch_copy_cols(int dtype, const void* src, int64_t lds, void* dst, int64_t ldd, int col0, int M, int C,
                      hipStream_t stream);

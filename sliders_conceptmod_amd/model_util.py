@@ -286,6 +286,26 @@ def _unet_from_dir(path: str, dtype):
     return unet
 
 
+def _clip_from_dir(path: str, sub: str):
+    """<path>/<sub>/config.json + model.safetensors (transformers layout, safe loader only) -> native CLIP text encoder;
+    `architectures` tells CLIPTextModel from CLIPTextModelWithProjection."""
+    import json
+    from safetensors.torch import load_file
+    from . import clip as PC
+    cj = json.load(open(os.path.join(path, sub, "config.json")))
+    proj = "CLIPTextModelWithProjection" in (cj.get("architectures") or [])
+    cfg = PC.CLIPTextConfig(vocab_size=cj["vocab_size"], hidden_size=cj["hidden_size"],
+                            intermediate_size=cj["intermediate_size"], num_hidden_layers=cj["num_hidden_layers"],
+                            num_attention_heads=cj["num_attention_heads"],
+                            max_position_embeddings=cj.get("max_position_embeddings", 77),
+                            hidden_act=cj.get("hidden_act", "quick_gelu"),
+                            projection_dim=cj.get("projection_dim") if proj else None,
+                            eos_token_id=cj.get("eos_token_id", 2))
+    enc = (PC.CLIPTextModelWithProjection if proj else PC.CLIPTextModel)(cfg)
+    enc.load_state_dict(load_file(os.path.join(path, sub, "model.safetensors")))
+    return enc
+
+
 def load_vae(pretrained_model_name_or_path: str, xl: bool = False):
     """The AutoencoderKL the image-slider scripts get next to the UNet (I/model_util.py:75,179): `synthetic://...`
     builds the SD / SD-XL VAE encoder architecture with seeded weights; a local diffusers directory is read from its
@@ -346,12 +366,14 @@ def load_models(pretrained_model_name_or_path: str, scheduler_name: str = "ddim"
         return None, enc, unet, scheduler
     if os.path.isdir(name):
         unet = _unet_from_dir(name, weight_dtype)
-        from transformers import CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer
+        # tokenisation is host text processing (transformers.CLIPTokenizer reads the directory's vocab files); the text
+        # encoders are the native ones (clip.py: transformers parameter names, arithmetic on the HIP engine)
+        from transformers import CLIPTokenizer
         toks = [CLIPTokenizer.from_pretrained(name, subfolder="tokenizer")]
-        encs = [CLIPTextModel.from_pretrained(name, subfolder="text_encoder")]
+        encs = [_clip_from_dir(name, "text_encoder")]
         if os.path.isdir(os.path.join(name, "text_encoder_2")):
             toks.append(CLIPTokenizer.from_pretrained(name, subfolder="tokenizer_2"))
-            encs.append(CLIPTextModelWithProjection.from_pretrained(name, subfolder="text_encoder_2"))
+            encs.append(_clip_from_dir(name, "text_encoder_2"))
         return toks, encs, unet, scheduler
     raise ValueError(f"cannot load '{name}': no network in this environment; pass a local diffusers directory or "
                      f"synthetic://sd1x | synthetic://sdxl")

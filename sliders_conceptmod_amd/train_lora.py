@@ -48,6 +48,10 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
     rank, world = parallel.world_info()
     parallel.sync_control_rng(device=device)
     noise_scheduler.dp_shard = (rank, world)
+    if isinstance(text_encoder, (list, tuple)):  # train_lora.py:64-65: text_encoder.to(device, dtype=weight_dtype).eval()
+        for te in text_encoder:
+            te.to(device, dtype=weight_dtype)
+            te.eval()
     unet.to(device, dtype=weight_dtype)
     unet.enable_xformers_memory_efficient_attention()
     unet.requires_grad_(False)

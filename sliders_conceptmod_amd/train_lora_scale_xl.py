@@ -65,6 +65,10 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     weight_dtype = config_util.parse_precision(config.train.precision)
     tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
         config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=True)
+    if isinstance(text_encoders, (list, tuple)):
+        for te in text_encoders:
+            te.to(device, dtype=weight_dtype)
+            te.eval()
     rank_, world = parallel.world_info()
     parallel.sync_control_rng(device=device)  # one control RNG (torch + random) for all ranks, before the adaptor init
     unet.to(device, dtype=weight_dtype)

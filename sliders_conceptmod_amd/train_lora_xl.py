@@ -51,6 +51,11 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
     rank_, world = parallel.world_info()
     parallel.sync_control_rng(device=device)
     noise_scheduler.dp_shard = (rank_, world)
+    if isinstance(text_encoders, (list, tuple)):  # train_lora_xl.py:72-75
+        for te in text_encoders:
+            te.to(device, dtype=weight_dtype)
+            te.requires_grad_(False)
+            te.eval()
     unet.to(device, dtype=weight_dtype)
     unet.requires_grad_(False)
     unet.eval()
