@@ -138,6 +138,79 @@ class LoRANetworkRef(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# DoRA (`--peft_type dora`: T/dora.py:53-162, T/train_lora_xl.py:87-90)
+# ----------------------------------------------------------------------------------------------------------
+class DoRAModuleRef(nn.Module):
+    """y = org(x) + F.linear(x, dW) * scale * multiplier with dW = (W + up down) * (dora_scale / ||W + up down||_col) - W,
+    the column norm (over the output dimension, one per input column) DETACHED (T/dora.py:124-162); dora_scale starts at
+    the frozen weight's column norms (:95-105).  Linear targets (what train_lora_xl.py adapts)."""
+
+    def __init__(self, lora_name: str, org_module: nn.Linear, multiplier=1.0, lora_dim=4, alpha=1):
+        super().__init__()
+        self.lora_name = lora_name
+        self.lora_dim = lora_dim
+        self.lora_down = nn.Linear(org_module.in_features, lora_dim, bias=False)
+        self.lora_up = nn.Linear(lora_dim, org_module.out_features, bias=False)
+        w = org_module.weight
+        self.dora_scale = nn.Parameter(torch.norm(w.detach().float(), dim=0, keepdim=True).to(w.dtype))  # [1, in]
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        self.scale = alpha / self.lora_dim
+        self.register_buffer("alpha", torch.tensor(alpha))
+        nn.init.kaiming_uniform_(self.lora_down.weight, a=1)
+        nn.init.zeros_(self.lora_up.weight)
+        self.multiplier = multiplier
+        self.org_module = [org_module]
+
+    def apply_to(self):
+        org = self.org_module[0]
+        self.org_forward = org.forward
+        org.forward = self.forward
+        self.org_weight = org.weight.detach()
+        del self.org_module
+
+    def forward(self, x):
+        w = self.org_weight
+        v = w + self.lora_up.weight @ self.lora_down.weight
+        norm = v.norm(dim=0, keepdim=True).detach()
+        dw = v * (self.dora_scale / norm) - w
+        return self.org_forward(x) + torch.nn.functional.linear(x, dw.to(x.dtype)) * self.scale * self.multiplier
+
+
+class DoRANetworkRef(nn.Module):
+    """T/dora.py:165-330.  NOTE the reference passes `self.alpha` into DoRAModule's `prefix` slot (:247-249 vs :57-65),
+    so every module keeps the default alpha = 1 whatever the network was given: reproduced."""
+
+    def __init__(self, unet, rank=4, multiplier=1.0, alpha=1.0, train_method="full", target_replace=("Attention",)):
+        super().__init__()
+        self.multiplier = multiplier
+        self.lora_dim = rank
+        self.alpha = alpha
+        self.unet_loras = []
+        for lora_name, _path, child, dup in select_lora_targets(unet, train_method, target_replace,
+                                                                with_duplicates=True):
+            m = DoRAModuleRef(lora_name, child, multiplier, rank, 1)
+            if not dup:
+                self.unet_loras.append(m)
+        for lora in self.unet_loras:
+            lora.apply_to()
+            self.add_module(lora.lora_name, lora)
+
+    def prepare_optimizer_params(self):
+        params = []
+        for lora in self.unet_loras:
+            params.extend(lora.parameters())
+        return [{"params": params}]
+
+    def __enter__(self):  # T/dora.py:322-324: 1.0, no lora_scale
+        for lora in self.unet_loras:
+            lora.multiplier = 1.0
+
+    def __exit__(self, *a):
+        for lora in self.unet_loras:
+            lora.multiplier = 0
+
+
+# ----------------------------------------------------------------------------------------------------------
 # step helpers (T/train_util.py)
 # ----------------------------------------------------------------------------------------------------------
 def concat_embeddings(unconditional, conditional, n_imgs):  # T/train_util.py:267-272

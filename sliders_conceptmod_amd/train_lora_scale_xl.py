@@ -26,12 +26,15 @@ from .train_lora_xl import encode_xl
 
 
 def image_slider_step(unet, network, scheduler, lat_low, lat_high, noise_low, noise_high, timestep, pos, neu,
-                      add_time_ids, scale: float, guidance_scale: float = 1.0):
-    """The two adapted passes + two backward()s of one image-slider step; returns (loss_high, loss_low)."""
+                      add_time_ids, scale: float, guidance_scale: float = 1.0, uncond=None):
+    """The two adapted passes + two backward()s of one image-slider step; returns (loss_high, loss_low).
+    SD-XL (`pos` / `neu` are PromptEmbedsXL): each prompt is paired with itself in the CFG batch
+    (I/train_lora-scale-xl.py:321-329).  SD-1.x (`pos` / `neu` / `uncond` are [1, 77, D] tensors): paired with the
+    unconditional prompt (I/train_lora-scale.py:283-318)."""
     bs = lat_high.shape[0]
+    xl = hasattr(pos, "pooled_embeds")
 
     def cond(e):
-        # the image sliders pair each prompt with itself in the CFG batch (I/train_lora-scale-xl.py:321-329)
         return dict(text_embeddings=train_util.concat_embeddings(e.text_embeds, e.text_embeds, bs),
                     add_text_embeddings=train_util.concat_embeddings(e.pooled_embeds, e.pooled_embeds, bs),
                     add_time_ids=train_util.concat_embeddings(add_time_ids, add_time_ids, bs))
@@ -40,8 +43,13 @@ def image_slider_step(unet, network, scheduler, lat_low, lat_high, noise_low, no
     for sgn, lat, noise, emb in ((+1.0, lat_high, noise_high, pos), (-1.0, lat_low, noise_low, neu)):
         network.set_lora_slider(scale=sgn * scale)
         with network:
-            pred = train_util.predict_noise_xl(unet, scheduler, timestep, lat, **cond(emb),
-                                               guidance_scale=guidance_scale)
+            if xl:
+                pred = train_util.predict_noise_xl(unet, scheduler, timestep, lat, **cond(emb),
+                                                   guidance_scale=guidance_scale)
+            else:
+                pred = train_util.predict_noise(unet, scheduler, timestep, lat,
+                                                train_util.concat_embeddings(uncond, emb, bs),
+                                                guidance_scale=guidance_scale)
         loss = torch.nn.functional.mse_loss(pred.float(), noise.float())  # fp32 at the loss, I/..-xl.py:282,338
         loss.backward()  # gradients of the two sides accumulate (I/train_lora-scale-xl.py:345,377)
         losses.append(loss.detach())
@@ -59,12 +67,15 @@ def _load_latent(path):
 _IMAGE_EXT = (".png", ".jpg", ".jpeg", ".webp")  # I/train_lora-scale-xl.py:217
 
 
-def train(config, prompts, device, folder_main, folders, scales, models=None, rank=4, vae=None, image_size=None):
+def train(config, prompts, device, folder_main, folders, scales, models=None, rank=4, vae=None, image_size=None,
+          xl=True):
     """`vae` (an AutoencoderKL, default: loaded next to the UNet) is only needed when the folders hold image files;
-    `image_size` is what the pairs are resized to (the reference hard-codes (512, 512), I/train_lora-scale-xl.py:220)."""
+    `image_size` is what the pairs are resized to (the reference hard-codes (512, 512) for SD-XL,
+    I/train_lora-scale-xl.py:220, and (256, 256) for SD-1.x, I/train_lora-scale.py:219).  `xl=False` is the SD-1.x twin
+    (train_lora_scale.py)."""
     weight_dtype = config_util.parse_precision(config.train.precision)
     tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
-        config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=True)
+        config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=xl)
     if isinstance(text_encoders, (list, tuple)):
         for te in text_encoders:
             te.to(device, dtype=weight_dtype)
@@ -86,9 +97,16 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     lr_scheduler = train_util.get_lr_scheduler(config.train.lr_scheduler, optimizer,
                                                max_iterations=config.train.iterations, lr_min=config.train.lr / 100)
     settings = prompts[0]
+    unc = None
     with torch.no_grad():
-        pos = encode_xl(text_encoders, tokenizers, settings.positive, device, weight_dtype)
-        neu = encode_xl(text_encoders, tokenizers, settings.neutral, device, weight_dtype)
+        if xl:
+            pos = encode_xl(text_encoders, tokenizers, settings.positive, device, weight_dtype)
+            neu = encode_xl(text_encoders, tokenizers, settings.neutral, device, weight_dtype)
+        else:
+            from .train_lora import encode
+            pos = encode(text_encoders, tokenizers, settings.positive, device, weight_dtype)
+            neu = encode(text_encoders, tokenizers, settings.neutral, device, weight_dtype)
+            unc = encode(text_encoders, tokenizers, settings.unconditional, device, weight_dtype)
     # folder <-> scale pairing by ORIGINAL index, as the reference does (folders[scales == s][0],
     # I/train_lora-scale-xl.py:213-214); a length mismatch raises as there (:452-453)
     if len(scales) != len(folders):
@@ -105,17 +123,18 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     if images:
         names = images
         if vae is None:
-            vae = model_util.load_vae(config.pretrained_model.name_or_path, xl=True)
+            vae = model_util.load_vae(config.pretrained_model.name_or_path, xl=xl)
         vae.to(device, dtype=weight_dtype)
         vae.requires_grad_(False)
         vae.eval()
-    size = image_size or (512, 512)
+    size = image_size or ((512, 512) if xl else (256, 256))
     save_path = Path(config.save.path)
     save_dtype = config_util.parse_precision(config.train.precision)
     for i in tqdm(range(config.train.iterations), disable=rank_ != 0):
         noise_scheduler.set_timesteps(config.train.max_denoising_steps, device=device)
         optimizer.zero_grad()
-        timesteps_to = torch.randint(1, config.train.max_denoising_steps - 1, (1,)).item()
+        # I/train_lora-scale-xl.py:191-193 draws from [1, max); the SD-1.x script from [1, max - 1) (I/train_lora-scale.py:186)
+        timesteps_to = torch.randint(1, config.train.max_denoising_steps - (0 if xl else 1), (1,)).item()
         scale_to_look = abs(random.choice(scales))
         f_low, f_high = folder_of[-scale_to_look], folder_of[scale_to_look]
         name = names[(random.randint(0, len(names) - 1) + rank_) % len(names)]  # ranks take different pairs
@@ -140,11 +159,11 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
             nl = noise_scheduler.add_noise(lat_low, noise_low, t).to(device)
             nh = noise_scheduler.add_noise(lat_high, noise_high, t).to(device)
             h, w = lat_low.shape[-2] * 8, lat_low.shape[-1] * 8
-        tid = train_util.get_add_time_ids(h, w, dtype=torch.float32).to(device)
+        tid = train_util.get_add_time_ids(h, w, dtype=torch.float32).to(device) if xl else None
         noise_scheduler.set_timesteps(1000)
         cur_t = noise_scheduler.timesteps[int(timesteps_to * 1000 / config.train.max_denoising_steps)]
         image_slider_step(unet, network, noise_scheduler, nl, nh, noise_low.to(device), noise_high.to(device), cur_t,
-                          pos, neu, tid, scale_to_look)
+                          pos, neu, tid, scale_to_look, uncond=unc)
         parallel.allreduce_mean_(network.flat.grad)
         optimizer.step()
         lr_scheduler.step()

@@ -393,6 +393,46 @@ def main():
             tensors[f"c3lier_init/{model}/{l.lora_name}.lora_down.weight"] = l.lora_down.weight.detach().clone()
         manifest[f"c3lier_init/{model}"] = {"seed": 1, "after_init_randint": int(torch.randint(0, 2 ** 31 - 1, (1,)))}
 
+    # ------------------------------------------------------------------ (9) DoRA (`--peft_type dora`, T/dora.py:53-162)
+    from conceptmod.textsliders import dora as ref_dora
+    for seed in range(2):
+        torch.manual_seed(200 + seed)
+        lin = torch.nn.Linear(24, 40)
+        mod = ref_dora.DoRAModule("lin", lin, multiplier=1.0, lora_dim=4, alpha=1.0 + seed)
+        scale0 = mod.dora_scale.detach().clone()
+        mod.lora_up.weight.data.normal_(0, 0.05)
+        mod.dora_scale.data.mul_(1.0 + 0.1 * torch.randn(mod.dora_scale.shape))
+        mod.apply_to()
+        mod.multiplier = 0.75
+        x = torch.randn(3, 7, 24, requires_grad=True)
+        y = lin(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        for k, v in {"w": lin.weight, "b": lin.bias, "down": mod.lora_down.weight, "up": mod.lora_up.weight,
+                     "dora_scale_init": scale0, "dora_scale": mod.dora_scale, "x": x, "y": y, "gy": gy, "gx": x.grad,
+                     "gdown": mod.lora_down.weight.grad, "gup": mod.lora_up.weight.grad,
+                     "gscale": mod.dora_scale.grad}.items():
+            tensors[f"dora_linear/{seed}/{k}"] = v.detach().clone().contiguous()
+        manifest[f"dora_linear/{seed}"] = {"multiplier": 0.75, "alpha": 1.0 + seed, "rank": 4, "scale": mod.scale,
+                                           "state_dict_keys": list(mod.state_dict().keys())}
+    dsel = {}
+    for model, cfg in [("sdxl", U.sdxl_config()), ("tiny_sdxl", U.tiny_sdxl_config()), ("tiny_sd1x", U.tiny_sd1x_config())]:
+        for method in ["noxattn", "full"]:
+            unet = U.UNet2DConditionModel(cfg) if model.startswith("tiny") else None
+            if unet is None:
+                continue
+            net = ref_dora.DoRANetwork(unet, rank=4, multiplier=1.0, delimiter="_", target_replace=["Attention"],
+                                       prefix="lora_unet", train_method=method)
+            names = [l.lora_name for l in net.unet_loras]
+            shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+            dsel[f"{model}/{method}"] = {
+                "n_modules": len(names), "n_params": sum(p.numel() for p in net.parameters()),
+                "names_sha": __import__("hashlib").sha256("\n".join(names).encode()).hexdigest(),
+                "shapes_sha": __import__("hashlib").sha256(json.dumps(shapes, sort_keys=True).encode()).hexdigest(),
+                "keys_head": list(net.state_dict().keys())[:4],
+            }
+    manifest["selection_dora"] = dsel
+
     save_file(tensors, os.path.join(OUT, "harness_goldens.safetensors"))
     with open(os.path.join(OUT, "harness_goldens.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -237,3 +237,47 @@ def test_c3lier_init_consumes_the_rng_like_the_reference(goldens, model):
     for k in keys:
         name = k.split("/")[2].rsplit(".lora_down.weight", 1)[0]
         torch.testing.assert_close(by_name[name].lora_down.weight.detach(), t[k], rtol=0, atol=0)
+
+
+# ---- DoRA (T/dora.py:53-162) ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1])
+def test_dora_linear_forward_backward(goldens, seed):
+    t, man = goldens
+    g = lambda k: t[f"dora_linear/{seed}/{k}"]
+    meta = man[f"dora_linear/{seed}"]
+    lin = torch.nn.Linear(24, 40)
+    lin.weight.data.copy_(g("w"))
+    lin.bias.data.copy_(g("b"))
+    mod = R.DoRAModuleRef("lin", lin, 1.0, 4, meta["alpha"])
+    assert mod.scale == meta["scale"]
+    torch.testing.assert_close(mod.dora_scale.detach(), g("dora_scale_init"), rtol=1e-6, atol=1e-7)
+    assert list(mod.state_dict().keys()) == meta["state_dict_keys"]
+    mod.lora_down.weight.data.copy_(g("down"))
+    mod.lora_up.weight.data.copy_(g("up"))
+    mod.dora_scale.data.copy_(g("dora_scale"))
+    mod.apply_to()
+    mod.multiplier = meta["multiplier"]
+    x = g("x").clone().requires_grad_(True)
+    y = lin(x)
+    y.backward(g("gy"))
+    torch.testing.assert_close(y.detach(), g("y"), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(x.grad, g("gx"), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(mod.lora_down.weight.grad, g("gdown"), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(mod.lora_up.weight.grad, g("gup"), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(mod.dora_scale.grad, g("gscale"), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("model", ["tiny_sd1x", "tiny_sdxl"])
+@pytest.mark.parametrize("method", ["noxattn", "full"])
+def test_dora_selection_matches_reference(goldens, model, method):
+    _, man = goldens
+    unet = U.UNet2DConditionModel(CFGS[model]())
+    net = R.DoRANetworkRef(unet, 4, 1.0, 1.0, method)
+    g = man["selection_dora"][f"{model}/{method}"]
+    names = [l.lora_name for l in net.unet_loras]
+    assert len(names) == g["n_modules"]
+    assert hashlib.sha256("\n".join(names).encode()).hexdigest() == g["names_sha"]
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert hashlib.sha256(json.dumps(shapes, sort_keys=True).encode()).hexdigest() == g["shapes_sha"]
+    assert list(net.state_dict().keys())[:4] == g["keys_head"]
+    assert sum(p.numel() for p in net.parameters()) == g["n_params"]

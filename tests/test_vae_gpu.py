@@ -83,7 +83,8 @@ def test_get_noisy_image_follows_the_reference_order():
     assert pv.config.scaling_factor == ov.cfg.scaling_factor
 
 
-def test_image_slider_trainer_encodes_image_folders(tmp_path):
+@pytest.mark.parametrize("xl", [True, False])
+def test_image_slider_trainer_encodes_image_folders(tmp_path, xl):
     """train_lora_scale_xl.train() on folders of PNG pairs (the reference's data layout): resize, VAE-encode on the engine,
     two-sided step, save.  Scales given in DESCENDING order with matching folders (pairing by original index)."""
     from PIL import Image
@@ -99,7 +100,8 @@ def test_image_slider_trainer_encodes_image_folders(tmp_path):
             arr = np.clip(rng.integers(0, 255, (80, 72, 3)) + bias, 0, 255).astype(np.uint8)
             Image.fromarray(arr).save(tmp_path / "data" / folder / name)
     cfg = CU.RootConfig(
-        prompts_file="unused", pretrained_model=CU.PretrainedModelConfig(name_or_path="synthetic://tiny_sdxl"),
+        prompts_file="unused",
+        pretrained_model=CU.PretrainedModelConfig(name_or_path="synthetic://tiny_sdxl" if xl else "synthetic://tiny_sd1x"),
         network=CU.NetworkConfig(type="c3lier", rank=4, alpha=1.0, training_method="noxattn"),
         train=CU.TrainConfig(precision="float16", noise_scheduler="ddim", iterations=3, lr=1e-4, optimizer="AdamW",
                              lr_scheduler="constant", max_denoising_steps=10),
@@ -108,14 +110,14 @@ def test_image_slider_trainer_encodes_image_folders(tmp_path):
     prompts = [PRU.PromptSettings(target="t", positive="big", neutral="small", unconditional="")]
     torch.manual_seed(0)
     net = train(cfg, prompts, torch.device("cuda:0"), str(tmp_path / "data"), ["big", "small"], [1, -1],
-                image_size=(64, 64))
+                image_size=(64, 64), xl=xl)
     out = tmp_path / "out" / "img_last.pt"
     assert out.exists()
     sd = torch.load(out, weights_only=True)
     assert any("conv1" in k for k in sd) and any("attn1" in k for k in sd)  # c3lier on the image trainer too
     assert float(net.flat_up.detach().abs().max()) > 0
     with pytest.raises(Exception, match="number of folders"):
-        train(cfg, prompts, torch.device("cuda:0"), str(tmp_path / "data"), ["big"], [1, -1], image_size=(64, 64))
+        train(cfg, prompts, torch.device("cuda:0"), str(tmp_path / "data"), ["big"], [1, -1], image_size=(64, 64), xl=xl)
     with pytest.raises(ValueError, match="no counterpart"):
         train(cfg, prompts, torch.device("cuda:0"), str(tmp_path / "data"), ["big", "small"], [1, -2],
-              image_size=(64, 64))
+              image_size=(64, 64), xl=xl)
