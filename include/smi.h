@@ -69,6 +69,10 @@ typedef struct smi_lora_site {
   int64_t off_up;
   int rank;
   float scale;
+  /* DoRA (conceptmod/textsliders/dora.py:53-162): element offset of this site's dora_scale [1, in] inside the UP flat
+   * buffer (gradients accumulate at the same offset of the up-gradient buffer); < 0: a plain LoRA site.
+   * dW = (W + up down) * (dora_scale / ||W + up down||_col) - W, y += scale * multiplier * x dW^T. */
+  int64_t off_dora;
 } smi_lora_site;
 
 /* Architecture of the diffusers AutoencoderKL ENCODER half (image sliders encode their image pairs with it every step:

@@ -49,7 +49,7 @@ class WeightC(C.Structure):
 
 class LoraSiteC(C.Structure):
     _fields_ = [("target", C.c_char_p), ("off_down", C.c_int64), ("off_up", C.c_int64), ("rank", C.c_int),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("off_dora", C.c_int64)]
 
 
 _lib = None
@@ -178,6 +178,7 @@ def make_sites(sites: Sequence[dict]):
         arr[i].off_up = s["off_up"]
         arr[i].rank = s["rank"]
         arr[i].scale = s["scale"]
+        arr[i].off_dora = s.get("off_dora", -1)
     return arr, keep
 
 

@@ -135,6 +135,9 @@ struct Lin {
   int rows_pad = 0;
   const void* sh_down = nullptr;  // [rows_pad, in]
   const void* sh_up = nullptr;    // [rows_pad, out] block-diagonal over the fused segments
+  // DoRA (T/dora.py): the adapted rows get a second GEMM against dW = lscale * ((W + up down) g / ||.||_col - W)
+  bool dora = false;
+  int dora_idx = -1;  // into smi_engine::dora_sites
 };
 struct Conv {
   const void* Wp = nullptr;   // forward pack [Cout][9*Cin]
@@ -254,6 +257,22 @@ struct smi_engine {
   std::vector<std::string> site_names;
   std::vector<char> site_used;
 
+  // DoRA sites: delta weights [out, in] (+ their transposes for dX) and column norms, rebuilt per adapted forward
+  std::vector<DoraSite> dora_sites;
+  std::vector<void*> dora_dWt;  // [in, out] per site
+  DoraSite* dora_sites_dev = nullptr;
+  float bw_mult = 0.f;
+  void dora_prepare(const float* down, const float* up, float m) {
+    if (dora_sites.empty() || dry || err) return;
+    if (launch_dora_prep(dtype, dora_sites_dev, dora_sites.data(), (int)dora_sites.size(), down, up, m, stream) != 0) {
+      err = true;
+      return;
+    }
+    for (size_t i = 0; i < dora_sites.size(); ++i) {
+      const DoraSite& d = dora_sites[i];
+      transpose_into(d.dW, dora_dWt[i], d.nseg * d.cs, d.K, d.nseg * d.cs, 0, false);
+    }
+  }
   // LoRA shadow operands
   std::vector<HostLoraPrepSite> prep_sites;
   void* prep_sites_dev = nullptr;
@@ -537,6 +556,38 @@ struct smi_engine {
     L.scale = first->scale;
     L.off_down = first->off_down;
     L.off_up = first->off_up;
+    if (first->off_dora >= 0) {  // DoRA site(s): all fused segments must be DoRA with adjacent scale vectors
+      for (size_t i = 0; i < targets.size(); ++i) {
+        const smi_lora_site* si = smap.find(targets[i])->second;
+        if (si->off_dora != first->off_dora + (int64_t)i * L.in) {
+          set_error("DoRA sites fused into '%s' must have adjacent dora_scale vectors", L.name.c_str());
+          err = true;
+          return;
+        }
+      }
+      if (L.rank > 32) {
+        set_error("DoRA rank %d > 32 on '%s'", L.rank, L.name.c_str());
+        err = true;
+        return;
+      }
+      L.dora = true;
+      L.dora_idx = (int)dora_sites.size();
+      DoraSite d{};
+      d.W = L.W;
+      d.off_down = L.off_down;
+      d.off_up = L.off_up;
+      d.off_dora = first->off_dora;
+      d.r = L.rank;
+      d.nseg = L.nseg;
+      d.K = L.in;
+      d.cs = L.out / L.nseg;
+      d.scale = L.scale;
+      d.dW = pack_alloc((size_t)L.out * L.in * esz());
+      d.cnorm = (float*)pack_alloc((size_t)L.nseg * L.in * sizeof(float));
+      dora_sites.push_back(d);
+      dora_dWt.push_back(pack_alloc((size_t)L.out * L.in * esz()));
+      return;  // no 16-bit shadow operands: the delta is a dense second GEMM
+    }
     const int rtot = L.rank * L.nseg;
     L.rows_pad = (rtot + 15) / 16 * 16;
     HostLoraPrepSite ps{};
@@ -592,6 +643,10 @@ struct smi_engine {
     c.sh_gw = reinterpret_cast<const void*>((uintptr_t)ps.dst_gw);
   }
   void finish_lora() {  // after build(): all Lin objects are at their final addresses
+    dora_sites_dev = (DoraSite*)pack_alloc(std::max<size_t>(dora_sites.size(), 1) * sizeof(DoraSite));
+    if (!dry && !err && !dora_sites.empty())
+      (void)hipMemcpyAsync(dora_sites_dev, dora_sites.data(), dora_sites.size() * sizeof(DoraSite), hipMemcpyHostToDevice,
+                           stream);
     lora_shadow = (char*)pack_alloc(std::max<size_t>(lora_shadow_elems, 8) * esz());
     prep_sites_dev = pack_alloc(std::max<size_t>(prep_sites.size(), 1) * sizeof(HostLoraPrepSite));
     if (!dry && !err && !prep_sites.empty())
@@ -786,7 +841,7 @@ struct smi_engine {
     }
     build_kv_group();
     finish_lora();
-    gscale = (float*)pack_alloc((2 * MAXS + 256) * sizeof(float));
+    gscale = (float*)pack_alloc((3 * MAXS + 258) * sizeof(float));  // + [2 MAXS..): min, 1/min, min / scale_j (DoRA)
     wjobs_cap = 11 * (sites.size() + 8);  // a conv site pushes 10 jobs (d_up + one d_down job per filter tap)
     wjobs_dev = (WgradJob*)pack_alloc(wjobs_cap * sizeof(WgradJob));
     for (size_t i = 0; i < sites.size(); ++i)
@@ -840,7 +895,7 @@ struct smi_engine {
     const int rtot = L.rank * L.nseg;
     float* xa = nullptr;
     const float lscale = mult * L.scale;
-    if (lon) {  // xa[M, rows_pad] = x * down^T as one MFMA GEMM on the 16-bit shadow copy (fp32 result)
+    if (lon && !L.dora) {  // xa[M, rows_pad] = x * down^T as one MFMA GEMM on the 16-bit shadow copy (fp32 result)
       xa = alloc_f32((size_t)MA(x) * L.rows_pad);
       GemmParams g;
       g.dtype = dtype;
@@ -874,7 +929,7 @@ struct smi_engine {
       p.res = res->p;
       p.ldr = res->cols;
     }
-    if (lon) {
+    if (lon && !L.dora) {
       p.lora_xa = xa;
       p.ld_xa = L.rows_pad;
       p.lora_up = lora_up + L.off_up;
@@ -888,6 +943,21 @@ struct smi_engine {
     RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
          (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     y->arow0 = x->arow0;
+    if (lon && L.dora && MA(x) > 0) {  // adapted rows: y += x dW^T (dW holds lscale), accumulated onto the main result
+      GemmParams d;
+      d.dtype = dtype;
+      d.A = PA(x);
+      d.lda = x->cols;
+      d.W = dora_sites[L.dora_idx].dW;
+      d.C = PA(y);
+      d.ldc = L.out;
+      d.res = PA(y);
+      d.ldr = L.out;
+      d.M = (int)MA(x);
+      d.N = L.out;
+      d.K = L.in;
+      RUNP(SMI_PROF_LORA, 2.0 * d.M * d.N * d.K, 0.0, launch_gemm(d, stream));
+    }
     y->ng = lon || x->ng || (res && res->ng);
     if (saving && y->ng) {
       const Lin* Lp = &L;
@@ -902,7 +972,33 @@ struct smi_engine {
     const int M = (int)MA(x);
     const int rtot = L->rank * L->nseg;
     float* dxa = nullptr;
-    if (lon) {
+    if (lon && L->dora) {
+      // G = dY^T X (dense fp32 [out, in]) from transposed 16-bit copies; rows of different samples carry different
+      // power-of-two loss scales, so dY is brought to the smallest one while it is transposed (min / scale_j <= 1)
+      const DoraSite& ds = dora_sites[L->dora_idx];
+      const int Mp = (M + 63) / 64 * 64;
+      const int rps = (int)(M / std::max(n_ad, 1));
+      void* dyT = alloc_t(L->out, Mp);
+      void* xT = alloc_t(L->in, Mp);
+      float* G = alloc_f32((size_t)L->out * L->in);
+      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_transpose_scaled(dtype, dy, L->out, dyT, M, L->out, Mp, gscale + 2 * MAXS + 2, rps, stream));
+      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_transpose_scaled(dtype, PA(x), x->cols, xT, M, L->in, Mp, nullptr, rps, stream));
+      GemmParams g;
+      g.dtype = dtype;
+      g.A = dyT;
+      g.lda = Mp;
+      g.W = xT;
+      g.C = G;
+      g.ldc = L->in;
+      g.out_f32 = 1;
+      g.M = L->out;
+      g.N = L->in;
+      g.K = Mp;
+      RUNP(SMI_PROF_LORA, 2.0 * g.M * g.N * M, 0.0, launch_gemm(g, stream));
+      // dW was built with lscale folded in: d(dW_unscaled) = lscale * G; the common loss scale (the minimum) divides out
+      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_dora_grads(dtype, ds, G, bw_down, bw_up, d_down, d_up, lscale / y->gmul, gscale + 2 * MAXS + 1, stream));
+    }
+    if (lon && !L->dora) {
       const int cs = L->out / L->nseg;
       const int r = L->rank;
       const int rp = L->rows_pad;
@@ -966,7 +1062,7 @@ struct smi_engine {
         p.res = gs.add;
         p.ldr = L->in;
       }
-      if (lon) {
+      if (lon && !L->dora) {
         p.lora_xa = dxa;
         p.ld_xa = L->rows_pad;
         p.lora_up = bw_down + L->off_down;  // A_cat [rtot, in] read as [in][rtot]
@@ -978,6 +1074,21 @@ struct smi_engine {
       }
       RUNP(SMI_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
            (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
+      if (lon && L->dora) {  // dX += dY dW (dW^T [in, out] is the K-contiguous operand), accumulated in place
+        GemmParams d;
+        d.dtype = dtype;
+        d.A = dy;
+        d.lda = L->out;
+        d.W = dora_dWt[L->dora_idx];
+        d.C = gs.out;
+        d.ldc = L->in;
+        d.res = gs.out;
+        d.ldr = L->in;
+        d.M = M;
+        d.N = L->in;
+        d.K = L->out;
+        RUNP(SMI_PROF_LORA, 2.0 * d.M * d.N * d.K, 0.0, launch_gemm(d, stream));
+      }
     }
   }
 
@@ -1733,6 +1844,7 @@ struct smi_engine {
     Ten* temb_act = silu(emb);
     if (!prep_sites.empty() && (dry || (lora_down && lora_up && mult != 0.f)))
       RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_prep(dtype, prep_sites_dev, (int)prep_sites.size(), lora_down, lora_up, lora_shadow, stream));
+    if (lora_down && lora_up && mult != 0.f) dora_prepare(lora_down, lora_up, mult);
 
     // ---- context as a [n*L, D] tensor (borrowed)
     tens->emplace_back();
@@ -1847,6 +1959,7 @@ struct smi_engine {
       bw_n_ad = n_adapted;
       bw_down = lora_down;
       bw_up = lora_up;
+      bw_mult = mult;
       tape_valid = true;
     }
     saving = false;
@@ -1884,6 +1997,15 @@ struct smi_engine {
     // one power-of-two loss scale PER SAMPLE (from max|d_eps[sample]|): a sample's backward arithmetic then does not
     // depend on which other samples share the batch -- W ranks on shards == one rank on the global batch
     RUN(launch_grad_scale(d_eps, n, (int64_t)cfg.out_channels * HW, gscale, MAXS, stream));
+    // the 16-bit LoRA operands / DoRA delta weights belong to the SAVED forward: an adapted no-grad pass in between
+    // (pre-roll) may have rebuilt them with other parameters or another multiplier -> rebuild from the saved ones
+    if (!prep_sites.empty() && bw_down && bw_up && bw_mult != 0.f)
+      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_prep(dtype, prep_sites_dev, (int)prep_sites.size(), bw_down, bw_up, lora_shadow, stream));
+    if (!dora_sites.empty() && bw_down && bw_up && bw_mult != 0.f) {
+      dora_prepare(bw_down, bw_up, bw_mult);
+      RUN(launch_scale_min(gscale, n, gscale + 2 * MAXS, stream));
+    }
+    mult = bw_mult;
     y->g = alloc_t(MA(y), 64);
     RUN(launch_nchw_to_nhwc_scaled(dtype, d_eps, y->g, n, cfg.out_channels, HW, 64, gscale, stream));
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();

@@ -367,6 +367,224 @@ int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, flo
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// DoRA kernels.  V = W + up down is never stored: r <= 32 multiply-adds per element rebuild it where it is needed.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int DORA_RMAX = 32;
+
+// grid (ceil(K / 64), nseg, n_sites); 4 waves split the rows of a segment, lane = column; fixed-order LDS combine
+template <typename T>
+__global__ __launch_bounds__(256) void dora_norm_kernel(const DoraSite* __restrict__ sites, const float* __restrict__ down,
+                                                        const float* __restrict__ up) {
+  __shared__ float red[4][64];
+  const DoraSite st = sites[blockIdx.z];
+  const int sgm = blockIdx.y;
+  if (sgm >= st.nseg) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (k < st.K) {
+    float a[DORA_RMAX];
+    for (int q = 0; q < st.r; ++q) a[q] = down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+    const T* W = reinterpret_cast<const T*>(st.W) + (int64_t)sgm * st.cs * st.K + k;
+    const float* B = up + st.off_up + (int64_t)sgm * st.cs * st.r;
+    for (int o = w; o < st.cs; o += 4) {
+      float v = to_f(W[(int64_t)o * st.K]);
+      for (int q = 0; q < st.r; ++q) v += B[(int64_t)o * st.r + q] * a[q];
+      acc += v * v;
+    }
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && k < st.K) st.cnorm[(int64_t)sgm * st.K + k] = sqrtf((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
+// grid (blocks, n_sites): dW[o][k] = lscale * ((W + up down)[o][k] * g[k] / n[k] - W[o][k]), 8 columns per thread
+template <typename T>
+__global__ __launch_bounds__(256) void dora_delta_kernel(const DoraSite* __restrict__ sites, const float* __restrict__ down,
+                                                         const float* __restrict__ up, float mult) {
+  const DoraSite st = sites[blockIdx.y];
+  const int k8n = st.K / 8;
+  const int64_t total = (int64_t)st.nseg * st.cs * k8n;
+  const float lscale = mult * st.scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k0 = (int)(i % k8n) * 8;
+    const int64_t ot = i / k8n;
+    const int sgm = (int)(ot / st.cs);
+    Pack8<T> wv, o;
+    wv.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(st.W) + ot * st.K + k0);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = to_f(wv.e[e]);
+    const float* B = up + st.off_up + ot * st.r;
+    for (int q = 0; q < st.r; ++q) {
+      const float b = B[q];
+      const float* a = down + st.off_down + ((int64_t)sgm * st.r + q) * st.K + k0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += b * a[e];
+    }
+    const float* g = up + st.off_dora + (int64_t)sgm * st.K + k0;
+    const float* n = st.cnorm + (int64_t)sgm * st.K + k0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(lscale * (v[e] * (g[e] / n[e]) - to_f(wv.e[e])));
+    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(st.dW) + ot * st.K + k0) = o.u;
+  }
+}
+
+// dst[c][m] = src[m][c] * f[m / rps] through a 64 x 64 LDS tile (coalesced both ways); columns m >= M are zero
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_scaled_kernel(const T* __restrict__ src, int64_t lds, T* __restrict__ dst,
+                                                               int M, int C, int Mp, const float* __restrict__ f, int rps) {
+  __shared__ float tile[64][65];
+  const int tilesC = (C + 63) / 64;
+  const int tm = (blockIdx.x / tilesC) * 64, tc = (blockIdx.x % tilesC) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int m = tm + i, c = tc + tx;
+    float v = 0.f;
+    if (m < M && c < C) v = to_f(src[(int64_t)m * lds + c]) * (f ? f[m / rps] : 1.f);
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = tc + i, m = tm + tx;
+    if (c < C && m < Mp) dst[(int64_t)c * Mp + m] = from_f<T>(tile[tx][i]);
+  }
+}
+
+// column-wise gradients: grid (ceil(K / 64), nseg): d(g)[k] = a * sum_o G V / n;  d(down)[q][k] = a * (g / n) * sum_o up[o][q] G[o][k]
+template <typename T>
+__global__ __launch_bounds__(256) void dora_col_grad_kernel(DoraSite st, const float* __restrict__ G,
+                                                            const float* __restrict__ down, const float* __restrict__ up,
+                                                            float* __restrict__ d_down, float* __restrict__ d_up, float alpha,
+                                                            const float* __restrict__ alpha_dev) {
+  __shared__ float red[4][DORA_RMAX + 1][64];
+  const int sgm = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float dg = 0.f, da[DORA_RMAX];
+  for (int q = 0; q < st.r; ++q) da[q] = 0.f;
+  if (k < st.K) {
+    float a[DORA_RMAX];
+    for (int q = 0; q < st.r; ++q) a[q] = down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+    const T* W = reinterpret_cast<const T*>(st.W) + (int64_t)sgm * st.cs * st.K + k;
+    const float* B = up + st.off_up + (int64_t)sgm * st.cs * st.r;
+    const float* Gs = G + (int64_t)sgm * st.cs * st.K + k;
+    for (int o = w; o < st.cs; o += 4) {
+      const float gv = Gs[(int64_t)o * st.K];
+      float v = to_f(W[(int64_t)o * st.K]);
+      for (int q = 0; q < st.r; ++q) {
+        const float b = B[(int64_t)o * st.r + q];
+        v += b * a[q];
+        da[q] += b * gv;
+      }
+      dg += gv * v;
+    }
+  }
+  red[w][0][lane] = dg;
+  for (int q = 0; q < st.r; ++q) red[w][1 + q][lane] = da[q];
+  __syncthreads();
+  if (w == 0 && k < st.K) {
+    const float al = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
+    const float n = st.cnorm[(int64_t)sgm * st.K + k];
+    const float g = up[st.off_dora + (int64_t)sgm * st.K + k];
+    const float s0 = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+    d_up[st.off_dora + (int64_t)sgm * st.K + k] += al * s0 / n;
+    for (int q = 0; q < st.r; ++q) {
+      const float sq = (red[0][1 + q][lane] + red[1][1 + q][lane]) + (red[2][1 + q][lane] + red[3][1 + q][lane]);
+      d_down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k] += al * (g / n) * sq;
+    }
+  }
+}
+
+// row-wise gradient: one wave per output row: d(up)[o][q] = a * sum_k G[o][k] (g[k] / n[k]) down[q][k]
+__global__ __launch_bounds__(256) void dora_row_grad_kernel(DoraSite st, const float* __restrict__ G,
+                                                            const float* __restrict__ down, const float* __restrict__ up,
+                                                            float* __restrict__ d_up, float alpha,
+                                                            const float* __restrict__ alpha_dev) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ot >= (int64_t)st.nseg * st.cs) return;
+  const int sgm = (int)(ot / st.cs);
+  float acc[DORA_RMAX];
+  for (int q = 0; q < st.r; ++q) acc[q] = 0.f;
+  const float* g = up + st.off_dora + (int64_t)sgm * st.K;
+  const float* n = st.cnorm + (int64_t)sgm * st.K;
+  for (int k = lane; k < st.K; k += 64) {
+    const float t = G[ot * st.K + k] * (g[k] / n[k]);
+    for (int q = 0; q < st.r; ++q) acc[q] += t * down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+  }
+  const float al = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
+  for (int q = 0; q < st.r; ++q) {
+    const float sum = wave_sum(acc[q]);
+    if (lane == 0) d_up[st.off_up + ot * st.r + q] += al * sum;
+  }
+}
+
+__global__ void scale_min_kernel(const float* __restrict__ sc, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float m = sc[0];
+    for (int j = 1; j < n; ++j) m = fminf(m, sc[j]);
+    out[0] = m;
+    out[1] = 1.f / m;
+    for (int j = 0; j < n; ++j) out[2 + j] = m / sc[j];
+  }
+}
+}  // namespace
+
+int launch_dora_prep(int dtype, const DoraSite* sites_dev, const DoraSite* sites_host, int n_sites, const float* down,
+                     const float* up, float mult, hipStream_t stream) {
+  if (n_sites <= 0) return 0;
+  int kmax = 0, segmax = 1;
+  for (int i = 0; i < n_sites; ++i) {
+    SMI_CHECK(sites_host[i].r >= 1 && sites_host[i].r <= DORA_RMAX && sites_host[i].K % 8 == 0, "dora: rank %d, K %d",
+              sites_host[i].r, sites_host[i].K);
+    kmax = std::max(kmax, sites_host[i].K);
+    segmax = std::max(segmax, sites_host[i].nseg);
+  }
+  dim3 gn(cdiv(kmax, 64), segmax, n_sites), gd(128, n_sites);
+  if (dtype == DT_F16) {
+    hipLaunchKernelGGL(dora_norm_kernel<f16>, gn, dim3(256), 0, stream, sites_dev, down, up);
+    hipLaunchKernelGGL(dora_delta_kernel<f16>, gd, dim3(256), 0, stream, sites_dev, down, up, mult);
+  } else {
+    hipLaunchKernelGGL(dora_norm_kernel<bf16>, gn, dim3(256), 0, stream, sites_dev, down, up);
+    hipLaunchKernelGGL(dora_delta_kernel<bf16>, gd, dim3(256), 0, stream, sites_dev, down, up, mult);
+  }
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_transpose_scaled(int dtype, const void* src, int64_t lds, void* dst, int M, int C, int Mp, const float* f,
+                            int rows_per_sample, hipStream_t stream) {
+  const int grid = cdiv(Mp, 64) * cdiv(C, 64);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(transpose_scaled_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, lds, (f16*)dst, M, C, Mp, f, rows_per_sample);
+  else
+    hipLaunchKernelGGL(transpose_scaled_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, lds, (bf16*)dst, M, C, Mp, f, rows_per_sample);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_dora_grads(int dtype, const DoraSite& site, const float* G, const float* down, const float* up,
+                      float* d_down, float* d_up, float alpha, const float* alpha_dev, hipStream_t stream) {
+  dim3 gc(cdiv(site.K, 64), site.nseg);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(dora_col_grad_kernel<f16>, gc, dim3(256), 0, stream, site, G, down, up, d_down, d_up, alpha, alpha_dev);
+  else
+    hipLaunchKernelGGL(dora_col_grad_kernel<bf16>, gc, dim3(256), 0, stream, site, G, down, up, d_down, d_up, alpha, alpha_dev);
+  hipLaunchKernelGGL(dora_row_grad_kernel, dim3(cdiv(site.nseg * site.cs, 4)), dim3(256), 0, stream, site, G, down, up,
+                     d_up, alpha, alpha_dev);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_scale_min(const float* scale_buf, int n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(scale_min_kernel, dim3(1), dim3(64), 0, stream, scale_buf, n, out);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
 // Fills the launch geometry of one job (host): column-block width, M-split, scratch need.
 void wgrad_job_plan(WgradJob& j) {
   const int cols8 = j.K / 8;

@@ -39,8 +39,8 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
     """`optimizer_kwargs` (not in the reference signature) overrides keyword arguments of the hard-coded AdamW
     (train_lora_xl.py:104), e.g. {"eps": 1e-3} for the element-wise trajectory parity test; the per-step losses of the
     run are left in `network.training_losses`."""
-    if peft_type != "lora":
-        raise NotImplementedError("--peft_type dora (conceptmod/textsliders/dora.py) is a 'next' row; only lora is built")
+    if peft_type not in ("lora", "dora"):
+        raise ValueError(f"peft_type must be lora or dora, got {peft_type}")
     save_path = Path(config.save.path)
     weight_dtype = config_util.parse_precision(config.train.precision)
     save_weight_dtype = config_util.parse_precision(config.train.precision)
@@ -59,9 +59,13 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
     unet.to(device, dtype=weight_dtype)
     unet.requires_grad_(False)
     unet.eval()
-    network = LoRANetwork(unet, rank=rank, multiplier=1.0, delimiter="_", target_replace=["Attention"],
-                          prefix="lora_unet", train_method=config.network.training_method).to(device,
-                                                                                              dtype=weight_dtype)
+    if peft_type == "dora":  # train_lora_xl.py:87-90
+        from .dora import DoRANetwork as peft_class
+    else:
+        peft_class = LoRANetwork
+    network = peft_class(unet, rank=rank, multiplier=1.0, delimiter="_", target_replace=["Attention"],
+                         prefix="lora_unet", train_method=config.network.training_method).to(device,
+                                                                                             dtype=weight_dtype)
     parallel.broadcast_(network.flat.data)
     okw = dict(lr=1e-4, weight_decay=1e-6)
     okw.update(optimizer_kwargs or {})

@@ -360,3 +360,65 @@ def test_c3lier_forward_and_gradients_match_oracle(model, method):
           ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert glob < 8e-3, glob
     assert all(v < 2.5e-2 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+@pytest.mark.parametrize("method", ["noxattn", "full"])
+def test_dora_forward_and_gradients_match_oracle(model, method):
+    """`--peft_type dora` (T/dora.py:124-162, T/train_lora_xl.py:87-90): dW = (W + up down) g / ||W + up down||_col - W as
+    a second GEMM on the adapted rows; gradients of lora_down / lora_up / dora_scale through the dense G = dY^T X against
+    the oracle's autograd (oracle.slider_ref.DoRAModuleRef, pinned to the reference's own module by
+    tests/test_oracle_golden.py::test_dora_linear_forward_backward)."""
+    import sliders_conceptmod_amd.dora as D
+    import sliders_conceptmod_amd.unet as PU
+    dtype = torch.float16
+    ocfg = CFGS[model]()
+    ou = OU.init_synthetic_(OU.UNet2DConditionModel(ocfg), seed=0).requires_grad_(False).eval()
+    pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(ocfg)))
+    pu.load_state_dict(ou.state_dict())
+    torch.manual_seed(1)
+    onet = R.DoRANetworkRef(ou, 4, 1.0, 1.0, method)
+    torch.manual_seed(1)
+    pnet = D.DoRANetwork(pu, rank=4, multiplier=1.0, target_replace=["Attention"], train_method=method)
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+            assert lo.lora_name == lp.lora_name
+            torch.testing.assert_close(lp.lora_down.weight, lo.lora_down.weight, rtol=0, atol=0)
+            torch.testing.assert_close(lp.dora_scale, lo.dora_scale, rtol=1e-6, atol=1e-7)
+            w = torch.randn(lo.lora_up.weight.shape, generator=g) * 0.05
+            sc = 1.0 + 0.1 * torch.randn(lo.dora_scale.shape, generator=g)
+            lo.lora_up.weight.copy_(w)
+            lp.lora_up.weight.copy_(w)
+            lo.dora_scale.mul_(sc)
+            lp.dora_scale.mul_(sc)
+    pu = pu.to("cuda", dtype).requires_grad_(False).eval()
+    pnet.to("cuda")
+    x, ctx, add = inputs(ocfg, 2, 16)
+    gy = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(9)) * 1e-4
+    with torch.no_grad():
+        onet.__exit__(None, None, None)
+        off = ou(x, 499.0, ctx, add).sample
+    with onet:
+        ref = ou(x, 499.0, ctx, add).sample
+    (ref * gy).sum().backward()
+    with pnet:
+        got = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+    (got * gy.cuda()).sum().backward()
+    e = rel(got, ref)
+    assert rel(ref, off) > 1e-3 and e < LOOSE[dtype], (rel(ref, off), e)
+    errs = {}
+    for what in ("down", "up", "scale"):
+        num = den = 0.0
+        for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
+            a, b = {"down": (lp.lora_down.grad, lo.lora_down.weight.grad), "up": (lp.lora_up.grad, lo.lora_up.weight.grad),
+                    "scale": (lp.dora_scale_grad, lo.dora_scale.grad)}[what]
+            assert b is not None and float(b.abs().max()) > 0
+            num += float((a.cpu() - b).norm() ** 2)
+            den += float(b.norm() ** 2)
+        errs[what] = (num / den) ** 0.5
+    print(f"{model} {method} dora: eps {e:.2e}, grads " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert all(v < 8e-3 for v in errs.values()), errs
+    pnet.__exit__(None, None, None)
+    with torch.no_grad():
+        assert rel(pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample, off) < LOOSE[dtype]

@@ -416,3 +416,24 @@ def test_native_preroll_matches_the_oracle(sched_name, model):
     e = float((got.cpu() - ref).norm() / ref.norm())
     print(f"{model} {sched_name}: 5-step pre-roll vs oracle rel err {e:.2e}")
     assert e < 3e-3, e
+
+
+def test_xl_trainer_peft_type_dora(tmp_path):
+    """train_lora_xl.train(peft_type="dora") (T/train_lora_xl.py:87-90): DoRANetwork on the engine through the CLI code
+    path; the saved file strict-loads into the oracle's restatement of the reference's DoRANetwork."""
+    from safetensors.torch import load_file
+    from sliders_conceptmod_amd.train_lora_xl import train
+    from oracle import slider_ref as R
+    cfg, prompts, models = make("tiny_sdxl", tmp_path, True)
+    cfg.train.iterations = 3
+    torch.manual_seed(1)
+    net = train(cfg, prompts, torch.device("cuda:0"), rank=4, save_file=True, models=models, peft_type="dora")
+    assert len(net.training_losses) == 3 and all(l == l and l > 0 for l in net.training_losses)
+    sd = load_file(str(tmp_path / "t_last.safetensors"))
+    onet = R.DoRANetworkRef(OU.UNet2DConditionModel(OU.tiny_sdxl_config()), 4, 1.0, 1.0, "noxattn")
+    onet.load_state_dict(sd, strict=True)
+    assert any(k.endswith(".dora_scale") for k in sd)
+    assert float(net.flat_up.detach().abs().max()) > 0  # lora_up left zero: the adaptor trained
+    with pytest.raises(ValueError):
+        train(cfg, prompts, torch.device("cuda:0"), rank=4, save_file=False, models=make("tiny_sdxl", tmp_path, True)[2],
+              peft_type="ia3")
