@@ -77,6 +77,28 @@ def diffusion_xl(unet, scheduler, latents, text_embeddings, add_text_embeddings,
 
 
 @torch.no_grad()
+def slider_sweep_latents(unet, network, scheduler, latents, text_embeddings, scale: float, start_noise: int,
+                         guidance_scale: float = 7.5, num_inference_steps: int = 50, added_cond=None):
+    """The inference-side slider loop of the eval scripts (eval-scripts/generate_images_sd1.py:170-190,
+    generate_images_xl.py:327-343): denoise from `latents` (already x init_noise_sigma) with classifier-free guidance, the
+    adaptor OFF (set_lora_slider(0)) while t > start_noise and at `scale` afterwards, every UNet call inside `with network`.
+    `text_embeddings` = cat([uncond, cond]) as there; `added_cond` = (add_text_embeddings, add_time_ids) for SD-XL.
+    Returns the final latents (decoding them is the VAE decoder's job, outside this package)."""
+    scheduler.set_timesteps(num_inference_steps)
+    for t in scheduler.timesteps:
+        network.set_lora_slider(scale=0 if t > start_noise else scale)
+        with network:
+            if added_cond is None:
+                noise_pred = predict_noise(unet, scheduler, t, latents, text_embeddings, guidance_scale=guidance_scale)
+            else:
+                noise_pred = predict_noise_xl(unet, scheduler, t, latents, text_embeddings, added_cond[0], added_cond[1],
+                                              guidance_scale=guidance_scale)
+        latents = scheduler.step(noise_pred, t, latents).prev_sample
+    network.set_lora_slider(scale=1)
+    return latents
+
+
+@torch.no_grad()
 def get_noisy_image(img, vae, generator, unet, scheduler, total_timesteps: int = 1000, start_timesteps=0, **kwargs):
     """Image-slider front end (trainscripts/imagesliders/train_util.py:200-235), same signature and order of operations:
     preprocess -> vae.encode(image).latent_dist.sample(None) -> x vae.config.scaling_factor -> noise = randn(shape,

@@ -437,3 +437,33 @@ def test_xl_trainer_peft_type_dora(tmp_path):
     with pytest.raises(ValueError):
         train(cfg, prompts, torch.device("cuda:0"), rank=4, save_file=False, models=make("tiny_sdxl", tmp_path, True)[2],
               peft_type="ia3")
+
+
+def test_inference_side_slider_sweep_matches_oracle():
+    """Row f-4, second half: the eval scripts' sampling loop (E/generate_images_sd1.py:170-190) -- adaptor gated off while
+    t > start_noise, then on at the slider scale, CFG 7.5, DDIM -- on the engine vs the same loop on the oracle."""
+    import sliders_conceptmod_amd.model_util as MU
+    from sliders_conceptmod_amd import train_util as TU
+    from oracle import sched_ref as S, slider_ref as R
+    from test_engine_gpu import build_pair
+    ocfg, ou, onet, pu, pnet = build_pair("tiny_sd1x", torch.float16)
+    g = torch.Generator().manual_seed(4)
+    te = torch.cat([torch.randn(1, 77, ocfg.cross_attention_dim, generator=g) for _ in range(2)])
+    lat = torch.randn(1, 4, 16, 16, generator=g)
+    osch, psch = S.create_noise_scheduler_ref("ddim"), MU.create_noise_scheduler("ddim")
+    outs = {}
+    for scale in (0.0, 2.0, -2.0):
+        osch.set_timesteps(10)
+        x = lat.clone()
+        with torch.no_grad():
+            for t in osch.timesteps:
+                onet.set_lora_slider(0 if t > 600 else scale)
+                with onet:
+                    eps = R.predict_noise(ou, osch, t, x, te, guidance_scale=7.5)
+                x = osch.step(eps, t, x).prev_sample
+        got = TU.slider_sweep_latents(pu, pnet, psch, lat.cuda(), te.cuda().half(), scale, 600, 7.5, 10)
+        e = float((got.cpu() - x).norm() / x.norm())
+        outs[scale] = got
+        print(f"slider sweep scale {scale:+.0f}: final latents vs oracle rel err {e:.2e}")
+        assert e < 5e-3, e
+    assert float((outs[2.0] - outs[0.0]).abs().max()) > 1e-3 and float((outs[2.0] - outs[-2.0]).abs().max()) > 1e-3
