@@ -118,6 +118,7 @@ __global__ void lora_prep_kernel(const LoraPrepSite* __restrict__ sites, const f
 template <typename T, int R>
 __global__ __launch_bounds__(256) void lora_wgrad_grouped_partial_kernel(const WgradJob* __restrict__ jobs, int njobs) {
   __shared__ float red[256 * 8];
+  __shared__ float ps[128 * 32];  // the workgroup's rows of P (x row scale), staged once: [row][all segments' r columns]
   __shared__ int jsel;
   if (threadIdx.x == 0) {  // last job whose first workgroup is <= blockIdx.x (jobs of one class are contiguous)
     int lo = 0, hi = njobs - 1;
@@ -141,7 +142,22 @@ __global__ __launch_bounds__(256) void lora_wgrad_grouped_partial_kernel(const W
   const int row1 = min(jb.M, row0 + jb.rows_per_wg);
   const int r = jb.r;
   const T* X = reinterpret_cast<const T*>(jb.X);
-  const float* P = jb.P + (jb.seg_cols ? ((col8 * 8) / jb.seg_cols) * r : 0);
+  const int segoff = jb.seg_cols ? ((col8 * 8) / jb.seg_cols) * r : 0;
+  const float* P = jb.P + segoff;
+  // P is tiny (r floats per row) but was 17 load instructions per row and thread against ONE for X: stage the rows of
+  // this workgroup in LDS (all segments' columns, row scale folded in) and read them back as LDS broadcasts
+  const int pw = jb.seg_cols ? (jb.K / jb.seg_cols) * r : r;
+  const bool staged = pw <= 32 && jb.rows_per_wg <= 128;
+  if (staged) {
+    const int nrow = row1 - row0;
+    for (int i = tid; i < nrow * pw; i += 256) {
+      const int rr = i / pw, q = i - rr * pw;
+      const int m = row0 + rr;
+      const float rs = jb.row_scale ? jb.row_scale[m / jb.rows_per_sample] : 1.f;
+      ps[i] = jb.P[(int64_t)m * jb.ldp + q] * rs;
+    }
+    __syncthreads();
+  }
   float acc[R][8];
 #pragma unroll
   for (int q = 0; q < R; ++q)
@@ -172,9 +188,15 @@ __global__ __launch_bounds__(256) void lora_wgrad_grouped_partial_kernel(const W
         }
         const bool ld = ok && xrow >= 0;
         xv[u].u = ld ? *reinterpret_cast<const u32x4*>(X + xrow * jb.ldx + col8 * 8) : u32x4{0, 0, 0, 0};
-        const float rs = (ok && jb.row_scale) ? jb.row_scale[m / jb.rows_per_sample] : 1.f;
+        if (staged) {
+          const float* pr = ps + (ok ? (m - row0) * pw + segoff : 0);
 #pragma unroll
-        for (int q = 0; q < R; ++q) pv[u][q] = (ok && q < r) ? P[(int64_t)m * jb.ldp + q] * rs : 0.f;
+          for (int q = 0; q < R; ++q) pv[u][q] = (ok && q < r) ? pr[q] : 0.f;
+        } else {
+          const float rs = (ok && jb.row_scale) ? jb.row_scale[m / jb.rows_per_sample] : 1.f;
+#pragma unroll
+          for (int q = 0; q < R; ++q) pv[u][q] = (ok && q < r) ? P[(int64_t)m * jb.ldp + q] * rs : 0.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
