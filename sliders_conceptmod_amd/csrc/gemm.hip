@@ -19,6 +19,8 @@
 
 #include "kernels.h"
 
+#include <mutex>
+
 namespace smi {
 
 namespace {
@@ -330,7 +332,7 @@ bool gemm_geglu_supported(const GemmParams& p) { return gemm_mode() != 3 && gemm
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 struct TuneKey {
-  int v[14];
+  int v[18];
   bool operator==(const TuneKey& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
 };
 struct TuneHash {
@@ -364,11 +366,16 @@ int launch_candidate(const GemmParams& p, int cand, hipStream_t stream) {
 }
 int tuned_choice(const GemmParams& p, hipStream_t stream) {
   TuneKey key;
-  const int kv[14] = {(int)p.dtype, (int)p.conv, p.M, p.N, p.K, (int)(p.conv ? p.Cin : p.lda),
+  const int kv[18] = {(int)p.dtype, (int)p.conv, p.M, p.N, p.K, (int)(p.conv ? p.Cin : p.lda),
                       (int)(p.stride * 4 + p.upsample * 2 + p.transposed), (int)(p.res != nullptr), p.lora_r,
                       (int)(p.geglu_out != nullptr), (int)p.out_f32, (int)(p.bias != nullptr),
-                      (int)(p.rowvec != nullptr), (int)(p.conv ? p.Hin * 65536 + p.Win : p.ldc)};
+                      (int)(p.rowvec != nullptr), (int)(p.conv ? p.Hin * 65536 + p.Win : p.ldc),
+                      (int)(p.res ? p.ldr : 0), p.lora_seg, p.pad, (int)(p.res == p.C) + 2 * (int)(p.lora_r > 0 && p.up_sn == 1)};
   memcpy(key.v, kv, sizeof(kv));
+  // one tuner at a time (several engines / host threads may share the process-wide cache); the timing launches run on
+  // the caller's stream -- since the engine dropped its second stream nothing else executes beside them
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   auto& cache = tune_cache();
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;

@@ -333,3 +333,30 @@ def test_step_ops_match_torch(lib):
     xr = x.clone()
     chk(lib, lib.smi_sched_step(P(x), P(e), P(nz), 0.9, -0.2, 0.05, n, None))
     torch.testing.assert_close(x, 0.9 * xr - 0.2 * e + 0.05 * nz, rtol=1e-6, atol=1e-6)
+
+
+def test_gemm_generations_are_bit_identical_per_epilogue_class():
+    """The tile autotuner (csrc/gemm.hip) may serve a (shape, epilogue) key with any kernel generation / tile layout;
+    that is only sound while they all produce the SAME BITS.  One op per key class -- full LoRA epilogue (bias + residual
+    + rank-r delta), fp32 output, fused GEGLU, 3x3 conv -- hashed in separate processes under every SMI_GEMM override
+    (ADVICE r1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("128", "256", "160", "64", "8ph", ""):
+        env = dict(os.environ)
+        env.pop("SMI_GEMM", None)
+        if mode:
+            env["SMI_GEMM"] = mode
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_digest.py")], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        res[mode or "auto"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    base = res["128"]
+    assert len(base) >= 20
+    for mode, d in res.items():
+        diff = [k for k in base if d[k] != base[k]]
+        assert not diff, f"SMI_GEMM={mode} differs from the 128x128 kernel on {diff}"
