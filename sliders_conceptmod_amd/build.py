@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsmi_hip.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "attention.hip", "norm.hip", "elementwise.hip", "lora.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "gemm4.hip", "attention.hip", "norm.hip", "elementwise.hip", "lora.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # attention: the softmax works on MFMA results every tile; with the default AGPR-form MFMA hipcc shuttles every
 # accumulator through v_accvgpr_read/write (481 moves per key tile, the kernel was VALU-bound at 91 % VALU busy).

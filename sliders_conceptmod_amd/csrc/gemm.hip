@@ -298,13 +298,15 @@ bool gemm2_geglu_supported(const GemmParams& p);
 int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream);
 bool gemm3_supported(const GemmParams& p);
 int launch_gemm3(const GemmParams& p, hipStream_t stream);
+bool gemm4_supported(const GemmParams& p);
+int launch_gemm4(const GemmParams& p, hipStream_t stream);
 
 // SMI_GEMM=v1 forces the register-staged kernel, SMI_GEMM=128 / 256 forces a v2 tile height (A/B experiments)
 static int gemm_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SMI_GEMM");
-    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : (!strcmp(e, "64w") ? 11 : 0)))))))))));
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : (!strcmp(e, "64w") ? 11 : (!strcmp(e, "5ph") ? 12 : (!strcmp(e, "no5ph") ? 13 : 0)))))))))))));
   }
   return mode;
 }
@@ -355,10 +357,11 @@ bool tune_enabled() {
   return on == 1;
 }
 // candidate codes: 0 = heuristic, 1 = v2 128x128 (8 waves), 2 = v2 256x128, 4 = v2 128x160, 7 = v2 64x128,
-// 100 = v3 8-phase
+// 100 = v3 8-phase, 200 = v4 256x320 persistent
 int launch_candidate(const GemmParams& p, int cand, hipStream_t stream) {
+  if (cand == 200 && gemm4_supported(p)) return launch_gemm4(p, stream);
   if (cand == 100 && gemm3_supported(p)) return launch_gemm3(p, stream);  // (layout re-checked: the key is shape-only)
-  if (cand == 0 || cand == 100) {
+  if (cand == 0 || cand == 100 || cand == 200) {
     if (gemm3_wanted(p) && gemm3_supported(p)) return launch_gemm3(p, stream);
     return launch_gemm2(p, 0, stream);
   }
@@ -379,7 +382,7 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
   auto& cache = tune_cache();
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
-  int cands[6], nc = 0;
+  int cands[8], nc = 0;
   cands[nc++] = 0;
   const bool plain_conv = p.conv && p.stride == 1 && !p.upsample && !p.transposed;
   if (!p.conv || plain_conv) {
@@ -388,6 +391,7 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
     if (p.N % 160 == 0 && (!p.geglu_out || p.N % 320 == 0)) cands[nc++] = 4;
     if (gemm3_supported(p) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) cands[nc++] = 100;
     if (!p.conv && (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) <= 512) cands[nc++] = 7;  // 64 x 128 tiles for small grids
+    if (gemm4_supported(p) && (int64_t)(p.M / 256) * (p.N / 320) >= 128) cands[nc++] = 200;
   }
   int best = 0;
   if (nc > 1) {
@@ -447,6 +451,8 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   }
   // v2 (LDS-DMA staging, full-row epilogue) serves dense GEMMs and convs; SMI_GEMM=convv1 keeps convs on v1, =v1 all
   // v3 (256x256 tile, 8-phase schedule): SMI_GEMM=8ph forces it wherever its layout rules hold, =no8ph disables it
+  // v4 (256x320 tile, persistent): SMI_GEMM=5ph forces it wherever its layout rules hold
+  if (gemm_mode() == 12 && gemm4_supported(p)) return launch_gemm4(p, stream);
   if ((gemm_mode() == 6 || ((gemm_mode() == 0 || gemm_mode() == 10) && gemm3_wanted(p))) && gemm3_supported(p))
     return launch_gemm3(p, stream);
   if (gemm_mode() != 3 && gemm2_supported(p) && (!p.conv || gemm_mode() != 4)) {

@@ -1,0 +1,417 @@
+// MFMA GEMM, fourth generation: 256 x 320 tile, persistent, five phases per 64-deep K-tile, ONE LDS-DMA pipeline that
+// runs on across output tiles.
+//
+// Why another tile.  Every channel count of the SD / SD-XL UNets is a multiple of 320 (320 / 640 / 1280 and the fused
+// 1920 / 2560 / 3840 / 5120 / 10240 widths) and none of the narrow ones is a multiple of 256: gemm3.hip's 256 x 256 tile
+// turns the N = 1280 layers into 64 x 5 = 320 tiles = 1.25 rounds of the 256 CUs (they ran on gemm2.hip's 128 x 160 tile
+// at 600-765 TF/s instead), N = 640 into 2.5 column tiles, and q|k|v (N = 3840) into 3.75 rounds.  With BN = 320 the
+// level-2 GEMMs of the batched step are exactly 1 (N = 1280), 3 (q|k|v) and 4 (ff.net.2: K = 5120, still 1 round)
+// rounds.  What the persistent form adds: a workgroup keeps its DMA pipeline full across the tile boundary (the next
+// tile's first two K-tiles are already staged when the epilogue starts), and the epilogue writes straight from the
+// accumulator registers (a lane owns 8 consecutive output columns), so it needs neither LDS nor a barrier.
+//
+// Geometry.  8 waves as 4 (M) x 2 (N); per-wave output 64 x 160 = acc[10 n-frags][4 m-frags] (160 accumulator
+// registers).  LDS: two K-tile buffers of A (256 rows x 128 B = 4 units of 8 KiB) + B (320 rows = 5 units); a unit is
+// what ONE global_load_lds_dwordx4 of the whole workgroup fills (64 rows).  B unit u holds the u-th pair of 16-column
+// fragments of BOTH wave columns, so phase u + 1 reads exactly one B unit:
+//     ph1  read B1 (4 ds_read_b128), A (8)    stage B4, A-u3 of tile t+1       16 MFMAs (4 m-frags x pair 0 x K = 64)
+//     ph2  read B2                             stage B5 of tile t+1              16 MFMAs
+//     ph3  read B3                             stage B1, A-u0 of tile t+2        16 MFMAs
+//     ph4  read B4                             stage B2, A-u1 of tile t+2        16 MFMAs
+//     ph5  read B5                             stage B3, A-u2 of tile t+2        16 MFMAs;  s_waitcnt vmcnt(6) first
+// Every unit is restaged two phases after its last read (cdna guide: "restage a buffer >= 2 phases after its last
+// ds_read"); the counted wait in ph5 leaves the three youngest stage groups (6 DMAs) in flight, i.e. K-tile t+1 has
+// landed, and t+1 is first read one phase (two barriers) later.  The two wave groups (waves 0-3 / 4-7: SIMD partners)
+// run staggered by one barrier as in gemm3.hip; they re-join for the epilogue and re-stagger after it.
+// "Tile t+1 / t+2" run on into the next output tile of this workgroup: the source of a stage is
+// (current tile, k) or (next tile, k - K).
+//
+// Requires M % 256 == 0, N % 320 == 0, K % 64 == 0, K >= 128 (everything else stays on gemm2 / gemm3).  Results are
+// bit-identical to the other generations: same K order per output element, same epilogue arithmetic.
+#include "kernels.h"
+
+#include <type_traits>
+
+namespace smi {
+namespace {
+
+constexpr int BM = 256, BN = 320, BK = 64;
+constexpr int UNIT = 64 * BK * 2;        // 8 KiB
+constexpr int ABYTES = 4 * UNIT;         // 32 KiB
+constexpr int KBUF = ABYTES + 5 * UNIT;  // 72 KiB per K-tile
+constexpr int SMEM4 = 2 * KBUF;          // 144 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+#define SMI_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
+  typedef typename TT<T>::v8 v8;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
+
+  const int nbn = p.N / BN, nbm = p.M / BM;
+  const int ntiles = nbn * nbm;
+  const int nk = p.K / BK;
+  const int G = gridDim.x;
+
+  // virtual tile id -> tile origin: XCD-contiguous chunks (ids congruent mod 8 share an XCD: G % 8 == 0 or one round),
+  // then gemm2's grouped rasterisation inside the chunk
+  const int ngrp = (nbn + 7) / 8;
+  const int GW = (nbn + ngrp - 1) / ngrp;
+  auto tile_origin = [&](int v, int& bm0, int& bn0) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    const int g = wg / (GW * nbm);
+    const int gw = min(nbn - g * GW, GW);
+    const int lw = wg - g * GW * nbm;
+    bm0 = __builtin_amdgcn_readfirstlane((lw / gw) * BM);
+    bn0 = __builtin_amdgcn_readfirstlane((g * GW + lw % gw) * BN);
+  };
+
+  // ---- LDS-DMA lane constants.  One instruction of the workgroup fills a unit: wave w covers its rows 8 w + (lane >> 3),
+  //      the lane's 16-byte slot (lane & 7) holds source chunk slot ^ (row & 7) (the read side applies the same XOR).
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const int r64 = wave * 8 + lrow;
+  const int chunk = lslot ^ lrow;
+  const uint32_t voffA = (uint32_t)r64 * (uint32_t)(p.lda * 2) + chunk * 16;
+  // B unit u, LDS row r = 32 wc' + 16 nip + fr  <-  W row (output column) 160 wc' + 32 u + 8 (fr >> 2) + 4 nip + (fr & 3):
+  // after the two MFMAs of a pair a lane owns 8 consecutive output columns
+  const uint32_t voffB =
+      (uint32_t)((r64 >> 5) * 160 + 8 * ((r64 & 15) >> 2) + 4 * ((r64 >> 4) & 1) + (r64 & 3)) * (uint32_t)(p.K * 2) +
+      chunk * 16;
+  const int64_t a_unit = (int64_t)64 * p.lda * 2;  // bytes between A units (64 rows)
+  const int64_t w_unit = (int64_t)32 * p.K * 2;    // bytes between B units (32 output columns)
+  const int ldsw = wave * 1024;                    // this wave's slice of a unit
+
+  // output tile state (wave-uniform)
+  int bm0, bn0, bm1 = 0, bn1 = 0;
+  int v = blockIdx.x;
+  tile_origin(v, bm0, bn0);
+  const char* a_cur = reinterpret_cast<const char*>(p.A) + (int64_t)bm0 * p.lda * 2;
+  const char* w_cur = reinterpret_cast<const char*>(p.W) + (int64_t)bn0 * p.K * 2;
+  const char* a_nxt = a_cur;
+  const char* w_nxt = w_cur;
+  bool has_next = false;
+
+  // stage unit u of K-tile tp (counted from the current output tile's first; tp >= nk runs into the next tile)
+  auto stage_a = [&](int u, int tp, unsigned char* buf) {
+    const char* base = tp < nk ? a_cur + (int64_t)tp * (BK * 2) : a_nxt + (int64_t)(tp - nk) * (BK * 2);
+    glds16(base + u * a_unit + voffA, buf + u * UNIT + ldsw);
+  };
+  auto stage_b = [&](int u, int tp, unsigned char* buf) {
+    const char* base = tp < nk ? w_cur + (int64_t)tp * (BK * 2) : w_nxt + (int64_t)(tp - nk) * (BK * 2);
+    glds16(base + u * w_unit + voffB, buf + ABYTES + u * UNIT + ldsw);
+  };
+
+  f32x4 acc[10][4];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 10; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment (i, kk) of a buffer: row = base + 16 i + fr, 16-byte chunk (4 kk + fq) ^ (fr & 7)
+  const int swz0 = (fq ^ (fr & 7)) << 4;
+  const int aoff0 = (wr * 64 + fr) * 128 + swz0, aoff1 = aoff0 ^ 64;
+  const int boff0 = ABYTES + (wc * 32 + fr) * 128 + swz0, boff1 = boff0 ^ 64;
+
+  v8 xa[2][4], wb[2][2];
+  auto rdA = [&](const unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Pack8<T> t0, t1;
+      t0.u = *reinterpret_cast<const u32x4*>(buf + aoff0 + i * 2048);
+      t1.u = *reinterpret_cast<const u32x4*>(buf + aoff1 + i * 2048);
+      xa[0][i] = t0.v;
+      xa[1][i] = t1.v;
+    }
+  };
+  auto rdB = [&](const unsigned char* buf, int u) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      Pack8<T> t0, t1;
+      t0.u = *reinterpret_cast<const u32x4*>(buf + boff0 + u * UNIT + i * 2048);
+      t1.u = *reinterpret_cast<const u32x4*>(buf + boff1 + u * UNIT + i * 2048);
+      wb[0][i] = t0.v;
+      wb[1][i] = t1.v;
+    }
+  };
+#define SMI_MMA5(U)                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) acc[2 * (U) + ni][mi] =                      \
+            TT<T>::mfma16(wb[kk][ni], xa[kk][mi], acc[2 * (U) + ni][mi]);                             \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+  } while (0)
+
+  // ---- prologue: K-tile 0 complete; B1 / A-u0, B2 / A-u1, B3 / A-u2 of K-tile 1 left in flight
+  {
+    unsigned char* b0 = smem;
+    unsigned char* b1 = smem + KBUF;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) stage_a(u, 0, b0);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) stage_b(u, 0, b0);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      stage_b(u, 1, b1);
+      stage_a(u, 1, b1);
+    }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 run one barrier behind waves 0-3
+  }
+
+  unsigned gk = 0;  // K-tiles done by this workgroup (buffer parity)
+  while (true) {
+    {
+      const int vn = v + G;
+      has_next = vn < ntiles;
+      if (has_next) {
+        tile_origin(vn, bm1, bn1);
+        a_nxt = reinterpret_cast<const char*>(p.A) + (int64_t)bm1 * p.lda * 2;
+        w_nxt = reinterpret_cast<const char*>(p.W) + (int64_t)bn1 * p.K * 2;
+      }
+    }
+    for (int t = 0; t < nk; ++t, ++gk) {
+      unsigned char* cur = smem + (gk & 1) * KBUF;
+      unsigned char* oth = smem + ((gk & 1) ^ 1) * KBUF;
+      const bool s1 = t + 1 < nk || has_next;  // K-tile t+1 exists (its B4 / A-u3 / B5 are still to be staged)
+      const bool s2 = t + 2 < nk || has_next;  // K-tile t+2 exists
+      // -------- phase 1
+      SMI_FENCE();
+      rdB(cur, 0);
+      SMI_FENCE();
+      rdA(cur);
+      SMI_FENCE();
+      if (s1) {
+        stage_b(3, t + 1, oth);
+        stage_a(3, t + 1, oth);
+      }
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SMI_FENCE();
+      SMI_MMA5(0);
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      // -------- phase 2
+      SMI_FENCE();
+      rdB(cur, 1);
+      SMI_FENCE();
+      if (s1) stage_b(4, t + 1, oth);
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SMI_FENCE();
+      SMI_MMA5(1);
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      // -------- phase 3
+      SMI_FENCE();
+      rdB(cur, 2);
+      SMI_FENCE();
+      if (s2) {
+        stage_b(0, t + 2, cur);
+        stage_a(0, t + 2, cur);
+      }
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SMI_FENCE();
+      SMI_MMA5(2);
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      // -------- phase 4
+      SMI_FENCE();
+      rdB(cur, 3);
+      SMI_FENCE();
+      if (s2) {
+        stage_b(1, t + 2, cur);
+        stage_a(1, t + 2, cur);
+      }
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SMI_FENCE();
+      SMI_MMA5(3);
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      // -------- phase 5
+      SMI_FENCE();
+      rdB(cur, 4);
+      SMI_FENCE();
+      if (s2) {
+        stage_b(2, t + 2, cur);
+        stage_a(2, t + 2, cur);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // all but the last three stage groups: K-tile t+1 has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SMI_FENCE();
+      SMI_MMA5(4);
+      SMI_FENCE();
+      __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // re-join: both wave groups run the epilogue together
+    SMI_FENCE();
+
+    // ---- epilogue, straight from the accumulators: per (mi, pair u) a lane holds 8 consecutive columns of one row
+    auto epilogue_pair = [&](auto Uc) {
+      constexpr int u = decltype(Uc)::value;
+      const int n = bn0 + wc * 160 + u * 32 + fq * 8;
+      float bv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+      if (p.bias) {
+        Pack8<T> b;
+        b.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = to_f(b.e[j]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = bm0 + wr * 64 + mi * 16 + fr;
+        float vv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vv[j] = acc[2 * u][mi][j];
+          vv[4 + j] = acc[2 * u + 1][mi][j];
+          acc[2 * u][mi][j] = 0.f;
+          acc[2 * u + 1][mi][j] = 0.f;
+        }
+        if (p.bias) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vv[j] += bv[j];
+        }
+        if (p.rowvec) {
+          Pack8<T> b;
+          b.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.rowvec) +
+                                                (int64_t)(m / p.rows_per_vec) * p.N + n);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vv[j] += to_f(b.e[j]);
+        }
+        if (p.lora_r > 0 && m >= p.lora_row0) {
+          const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
+          const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
+          if (p.up_sq == 1 && p.up_sn == p.lora_r && (p.lora_r & 3) == 0) {
+            float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int r0 = 0; r0 < p.lora_r; r0 += 4) {
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + r0);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * p.lora_r + r0);
+                d[j] += xv[0] * uv[0] + xv[1] * uv[1] + xv[2] * uv[2] + xv[3] * uv[3];
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vv[j] += d[j] * p.lora_scale;
+          } else if (p.up_sn == 1 && (p.up_sq & 3) == 0) {
+            float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < p.lora_r; ++r) {
+              const float xq = xrow[r];
+              const float* ar = p.lora_up + (int64_t)r * p.up_sq + n;
+              const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                d[j] += xq * a0[j];
+                d[4 + j] += xq * a1[j];
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vv[j] += d[j] * p.lora_scale;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
+              const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
+              float d = 0.f;
+              for (int r = 0; r < p.lora_r; ++r) d += xr[r] * up[r * p.up_sq];
+              vv[j] += d * p.lora_scale;
+            }
+          }
+        }
+        if (p.res) {
+          Pack8<T> b;
+          b.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vv[j] += to_f(b.e[j]);
+        }
+        if (p.out_f32) {
+          float* op = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+          *reinterpret_cast<f32x4*>(op) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{vv[4], vv[5], vv[6], vv[7]};
+        } else {
+          Pack8<T> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = from_f<T>(vv[j]);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) = o.u;
+        }
+      }
+    };
+    epilogue_pair(std::integral_constant<int, 0>{});
+    epilogue_pair(std::integral_constant<int, 1>{});
+    epilogue_pair(std::integral_constant<int, 2>{});
+    epilogue_pair(std::integral_constant<int, 3>{});
+    epilogue_pair(std::integral_constant<int, 4>{});
+    SMI_FENCE();
+    if (!has_next) break;
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // re-stagger
+    v += G;
+    bm0 = bm1;
+    bn0 = bn1;
+    a_cur = a_nxt;
+    w_cur = w_nxt;
+  }
+}
+
+template <typename T>
+int launch_t(const GemmParams& p, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    SMI_HIP(hipFuncSetAttribute((const void*)gemm_5ph_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM4));
+    attr_done = true;
+  }
+  const int ntiles = (p.M / BM) * (p.N / BN);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  hipLaunchKernelGGL((gemm_5ph_kernel<T>), dim3(grid), dim3(512), SMEM4, stream, p);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+bool gemm2_supported(const GemmParams& p);
+
+// dense GEMMs on whole 256 x 320 tiles
+bool gemm4_supported(const GemmParams& p) {
+  if (!gemm2_supported(p)) return false;
+  if (p.conv || p.geglu_out) return false;
+  if (p.M % BM != 0 || p.N % BN != 0 || p.K % BK != 0 || p.K < 2 * BK) return false;
+  if (p.lora_seg % 8 != 0) return false;
+  if (p.out_f32 && p.ldc % 4 != 0) return false;
+  if ((int64_t)BM * p.lda * 2 >= (1ll << 31) || (int64_t)BN * p.K * 2 >= (1ll << 31)) return false;  // 32-bit lane offsets
+  return true;
+}
+
+int launch_gemm4(const GemmParams& p, hipStream_t stream) {
+  if (p.dtype == DT_F16) return launch_t<f16>(p, stream);
+  return launch_t<bf16>(p, stream);
+}
+
+}  // namespace smi

@@ -1,0 +1,93 @@
+"""Race / correctness screen and A/B timing for the 256x320 persistent GEMM (gemm4.hip).
+
+Every shape is run (a) on the default selection with tuning off (gemm2 / gemm3 heuristics) and (b) forced onto gemm4
+(SMI_GEMM is read once per process, so the two arms are child processes writing their outputs' digests), compared with
+an fp32 torch matmul, bit-for-bit between the arms, and bit-for-bit across repeated runs of the same arm.
+
+    python tools/check_gemm4.py            # parent: runs both arms, compares digests, prints timings side by side
+"""
+import ctypes as C, hashlib, json, os, subprocess, sys
+
+SHAPES = [(256, 320, 128), (256, 320, 192), (512, 640, 320), (16384, 1280, 1280), (16384, 1280, 5120),
+          (16384, 3840, 1280), (65536, 640, 640), (65536, 640, 2560), (65536, 1920, 640), (4096, 1280, 1280),
+          (16384, 640, 5120), (16384, 5120, 1280), (65536, 320, 960), (16384, 10240, 1280), (4096, 1280, 10240)]
+
+
+def child(arm):
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sliders_conceptmod_amd import _native
+    lib = _native.lib()
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    out = {}
+    for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
+        for (M, N, K) in SHAPES:
+            for epi in (0, 1, 2):  # 0: plain, 1: bias + res, 2: bias + res + LoRA rank 4 on the rows >= M/2? (all rows)
+                if dt == torch.bfloat16 and epi == 2:
+                    continue
+                g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K + epi)
+                a = torch.randn(M, K, device="cuda", generator=g).to(dt)
+                w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dt)
+                bias = torch.randn(N, device="cuda", generator=g).to(dt) if epi else None
+                res = torch.randn(M, N, device="cuda", generator=g).to(dt) if epi else None
+                xa = torch.randn(M, 4, device="cuda", generator=g) if epi == 2 else None
+                up = torch.randn(N, 4, device="cuda", generator=g) if epi == 2 else None
+                ref = a.float() @ w.float().t()
+                if epi:
+                    ref = ref + bias.float() + res.float()
+                if epi == 2:
+                    ref = ref + 0.5 * (xa @ up.t())
+                first = None
+                nrep = 12 if M * N * K < 2e11 else 5
+                for rep in range(nrep):
+                    c = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+                    rc = lib.smi_op_gemm(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up),
+                                         4 if epi == 2 else 0, 0.5 if epi == 2 else 0.0, 0, None)
+                    assert rc == 0, _native.last_error()
+                    torch.cuda.synchronize()
+                    if first is None:
+                        first = c.clone()
+                        err = float((c.float() - ref).abs().max() / ref.abs().max())
+                    elif not torch.equal(c, first):
+                        err = float("inf")  # race
+                        break
+                # timing
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c = torch.empty(M, N, device="cuda", dtype=dt)
+                s.record()
+                for _ in range(10):
+                    lib.smi_op_gemm(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up),
+                                    4 if epi == 2 else 0, 0.5 if epi == 2 else 0.0, 0, None)
+                e.record()
+                torch.cuda.synchronize()
+                us = s.elapsed_time(e) * 100
+                dig = hashlib.sha256(first.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+                out[f"{code}:{M}x{N}x{K}:e{epi}"] = [err, dig, us]
+                print(f"[{arm}] {str(dt):15s} {M}x{N}x{K} epi={epi}: err {err:.2e}  {us:8.1f} us  "
+                      f"{2*M*N*K/us/1e6:7.1f} TF/s", flush=True)
+    json.dump(out, open(f"gpurun_out/check_gemm4_{arm}.json", "w"))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        child(sys.argv[1])
+        sys.exit(0)
+    os.makedirs("gpurun_out", exist_ok=True)
+    for arm, env in (("base", {"SMI_GEMM_TUNE": "0"}), ("v4", {"SMI_GEMM": "5ph"})):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), arm], env={**os.environ, **env})
+        if r.returncode != 0:
+            print(f"arm {arm} failed rc={r.returncode}")
+            sys.exit(1)
+    a = json.load(open("gpurun_out/check_gemm4_base.json"))
+    b = json.load(open("gpurun_out/check_gemm4_v4.json"))
+    bad = 0
+    for k in a:
+        ea, da, ta = a[k]
+        eb, db, tb = b[k]
+        tol = 2e-3 if k.startswith("0:") else 1.2e-2
+        ok = ea < tol and eb < tol and da == db
+        bad += 0 if ok else 1
+        print(f"{k:28s} base {ta:8.1f} us  v4 {tb:8.1f} us  x{ta/tb:5.2f}  err {ea:.1e}/{eb:.1e}  "
+              f"{'bit-identical' if da == db else 'DIFFERENT'}  {'ok' if ok else 'FAIL'}")
+    print("FAILED" if bad else "ALL OK")
+    sys.exit(1 if bad else 0)
