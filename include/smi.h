@@ -237,6 +237,13 @@ int smi_sched_step(float* x, const float* eps, const float* noise, float c_x, fl
 int smi_op_gemm(int dtype, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
                 const void* res, const float* lora_xa, const float* lora_up, int lora_r, float lora_scale,
                 int out_f32, void* stream);
+/* The batched-pass form of the adapted Linear (T/lora.py:134-138 under T/train_util.py:449-489's batched UNet call):
+ * rows m >= lora_row0 get + lora_scale * xa[m - lora_row0] up^T, rows below none (the frozen samples of the pass).
+ * lora_seg > 0: fused projections (q|k|v) -- column block n / lora_seg has its own [lora_seg, r] up matrix (adjacent in
+ * lora_up) and its own r columns of xa (row stride r * N / lora_seg). */
+int smi_op_gemm_rows(int dtype, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
+                     const void* res, const float* lora_xa, const float* lora_up, int lora_r, float lora_scale,
+                     int lora_row0, int lora_seg, void* stream);
 int smi_op_conv3x3(int dtype, const void* in, const void* w_packed, const void* bias, void* out, int nb, int hin,
                    int win, int cin, int cout, int stride, int upsample, int transposed, int hout, int wout,
                    void* stream);

@@ -91,6 +91,9 @@ _SIGS = {
     "smi_sched_step": (C.c_int, [C.c_void_p] * 3 + [C.c_float] * 3 + [C.c_int64, C.c_void_p]),
     "smi_op_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "smi_op_gemm_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int,
+                                   C.c_void_p]),
     "smi_op_conv3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 +
                        [C.c_void_p]),
     "smi_op_attention_fwd": (C.c_int, [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),

@@ -2497,6 +2497,33 @@ int smi_op_gemm(int dtype, const void* A, const void* W, void* C, int M, int N, 
   p.lora_scale = lora_scale;
   return launch_gemm(p, (hipStream_t)stream);
 }
+int smi_op_gemm_rows(int dtype, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
+                     const void* res, const float* lora_xa, const float* lora_up, int lora_r, float lora_scale,
+                     int lora_row0, int lora_seg, void* stream) {
+  GemmParams p;
+  p.dtype = dtype;
+  p.A = A;
+  p.lda = K;
+  p.W = W;
+  p.C = C;
+  p.ldc = N;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.bias = bias;
+  p.res = res;
+  p.ldr = N;
+  p.lora_xa = lora_xa;
+  p.ld_xa = (int64_t)lora_r * (lora_seg > 0 ? N / lora_seg : 1);
+  p.lora_up = lora_up;
+  p.up_sn = lora_r;
+  p.up_sq = 1;
+  p.lora_r = lora_xa ? lora_r : 0;
+  p.lora_seg = lora_seg;
+  p.lora_scale = lora_scale;
+  p.lora_row0 = lora_row0;
+  return launch_gemm(p, (hipStream_t)stream);
+}
 int smi_op_gemm_geglu(int dtype, const void* A, const void* W, const void* bias, void* out, void* proj, int M, int N,
                       int K, int proj_row0, void* stream) {
   GemmParams p;

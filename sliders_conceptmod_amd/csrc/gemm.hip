@@ -221,8 +221,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) {
           const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
           float d = 0.f;
-          for (int q = 0; q < p.lora_r; ++q) d += xrow[q] * up[q * p.up_sq];
-          v[j] += d * p.lora_scale;
+          for (int q = 0; q < p.lora_r; ++q) d = __builtin_fmaf(xrow[q], up[q * p.up_sq], d);
+          v[j] = __builtin_fmaf(d, p.lora_scale, v[j]);
         }
       }
       if (p.res) {

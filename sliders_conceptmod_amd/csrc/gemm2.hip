@@ -355,11 +355,11 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * p.lora_r + r0);
-              d[j] += xv[0] * uv[0] + xv[1] * uv[1] + xv[2] * uv[2] + xv[3] * uv[3];
+              d[j] = lora_fma4(d[j], xv, uv);
             }
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += d[j] * p.lora_scale;
+          for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(d[j], p.lora_scale, v[j]);
         } else if (full && p.up_sn == 1 && (p.up_sq & 3) == 0) {
           // backward (dX): "up" is lora_down [r_tot, K] read along K: 8 consecutive columns = two 16-byte loads per q
           float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -369,12 +369,12 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              d[j] += xq * a0[j];
-              d[4 + j] += xq * a1[j];
+              d[j] = __builtin_fmaf(xq, a0[j], d[j]);
+              d[4 + j] = __builtin_fmaf(xq, a1[j], d[4 + j]);
             }
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += d[j] * p.lora_scale;
+          for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(d[j], p.lora_scale, v[j]);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -382,8 +382,8 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
               const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
               const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
               float d = 0.f;
-              for (int r = 0; r < p.lora_r; ++r) d += xr[r] * up[r * p.up_sq];
-              v[j] += d * p.lora_scale;
+              for (int r = 0; r < p.lora_r; ++r) d = __builtin_fmaf(xr[r], up[r * p.up_sq], d);
+              v[j] = __builtin_fmaf(d, p.lora_scale, v[j]);
             }
           }
         }

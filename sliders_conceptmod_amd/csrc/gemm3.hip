@@ -326,11 +326,11 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * p.lora_r + r0);
-              d[j] += xv[0] * uv[0] + xv[1] * uv[1] + xv[2] * uv[2] + xv[3] * uv[3];
+              d[j] = lora_fma4(d[j], xv, uv);
             }
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += d[j] * p.lora_scale;
+          for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(d[j], p.lora_scale, v[j]);
         } else if (p.up_sn == 1 && (p.up_sq & 3) == 0) {
           float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int r = 0; r < p.lora_r; ++r) {
@@ -339,20 +339,20 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              d[j] += xq * a0[j];
-              d[4 + j] += xq * a1[j];
+              d[j] = __builtin_fmaf(xq, a0[j], d[j]);
+              d[4 + j] = __builtin_fmaf(xq, a1[j], d[4 + j]);
             }
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += d[j] * p.lora_scale;
+          for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(d[j], p.lora_scale, v[j]);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
             const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
             float d = 0.f;
-            for (int r = 0; r < p.lora_r; ++r) d += xr[r] * up[r * p.up_sq];
-            v[j] += d * p.lora_scale;
+            for (int r = 0; r < p.lora_r; ++r) d = __builtin_fmaf(xr[r], up[r * p.up_sq], d);
+            v[j] = __builtin_fmaf(d, p.lora_scale, v[j]);
           }
         }
       }

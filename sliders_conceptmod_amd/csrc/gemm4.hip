@@ -84,13 +84,19 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   const int lrow = lane >> 3, lslot = lane & 7;
   const int r64 = wave * 8 + lrow;
   const int chunk = lslot ^ lrow;
-  const uint32_t voffA = (uint32_t)r64 * (uint32_t)(p.lda * 2) + chunk * 16;
+  // "mix": a batched forward whose last quarter of the rows carries the LoRA delta (3 frozen passes + 1 adapted, the
+  // slider step) takes every tile as 192 frozen + 64 adapted rows -- A unit u (= wave row u) is 48 frozen rows + 16
+  // adapted ones, so each wave's fourth m-fragment is the adapted one and the delta's epilogue cost is spread evenly
+  // over all tiles and waves instead of quadrupling the epilogue of a quarter of the tiles (the launch waits for those).
+  const bool mix = p.lora_r > 0 && p.lora_row0 > 0 && 4 * (int64_t)p.lora_row0 == 3 * (int64_t)p.M;
+  const bool arow = mix && wave >= 6;  // this wave stages the adapted rows of a unit (wave-uniform)
+  const uint32_t voffA = (uint32_t)(arow ? r64 - 48 : r64) * (uint32_t)(p.lda * 2) + chunk * 16;
   // B unit u, LDS row r = 32 wc' + 16 nip + fr  <-  W row (output column) 160 wc' + 32 u + 8 (fr >> 2) + 4 nip + (fr & 3):
   // after the two MFMAs of a pair a lane owns 8 consecutive output columns
   const uint32_t voffB =
       (uint32_t)((r64 >> 5) * 160 + 8 * ((r64 & 15) >> 2) + 4 * ((r64 >> 4) & 1) + (r64 & 3)) * (uint32_t)(p.K * 2) +
       chunk * 16;
-  const int64_t a_unit = (int64_t)64 * p.lda * 2;  // bytes between A units (64 rows)
+  const int64_t a_unit = (int64_t)(mix ? (arow ? 16 : 48) : 64) * p.lda * 2;  // bytes between this wave's rows of A units
   const int64_t w_unit = (int64_t)32 * p.K * 2;    // bytes between B units (32 output columns)
   const int ldsw = wave * 1024;                    // this wave's slice of a unit
 
@@ -98,7 +104,9 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   int bm0, bn0, bm1 = 0, bn1 = 0;
   int v = blockIdx.x;
   tile_origin(v, bm0, bn0);
-  const char* a_cur = reinterpret_cast<const char*>(p.A) + (int64_t)bm0 * p.lda * 2;
+  // first row this wave stages for tile origin bm: plain bm; mix: frozen block 3/4 bm or adapted block row0 + bm/4
+  auto a_row0 = [&](int bm) { return mix ? (arow ? p.lora_row0 + (bm >> 2) : 3 * (bm >> 2)) : bm; };
+  const char* a_cur = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm0) * p.lda * 2;
   const char* w_cur = reinterpret_cast<const char*>(p.W) + (int64_t)bn0 * p.K * 2;
   const char* a_nxt = a_cur;
   const char* w_nxt = w_cur;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
       has_next = vn < ntiles;
       if (has_next) {
         tile_origin(vn, bm1, bn1);
-        a_nxt = reinterpret_cast<const char*>(p.A) + (int64_t)bm1 * p.lda * 2;
+        a_nxt = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm1) * p.lda * 2;
         w_nxt = reinterpret_cast<const char*>(p.W) + (int64_t)bn1 * p.K * 2;
       }
     }
@@ -272,6 +280,18 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
     SMI_FENCE();
 
     // ---- epilogue, straight from the accumulators: per (mi, pair u) a lane holds 8 consecutive columns of one row
+    // tile row of fragment mi: plain 64 wr + 16 mi + fr; mix: fragments 0-2 frozen rows, fragment 3 adapted rows
+    const int rowf = mix ? 3 * (bm0 >> 2) + wr * 48 + fr : bm0 + wr * 64 + fr;
+    const int rowa = mix ? p.lora_row0 + (bm0 >> 2) + wr * 16 + fr : bm0 + wr * 64 + 48 + fr;
+    auto row_of = [&](int mi) { return mi < 3 ? rowf + mi * 16 : rowa; };
+    const bool lora_tile = p.lora_r > 0 && (mix || bm0 + BM > p.lora_row0);
+    // forward-form delta (up [N, r] row-major, r % 4 == 0, r <= 16, a tile inside one fused segment) on the fp32 MFMA:
+    // D[16 cols][16 rows] = up-fragment [16 x 4] * xa-fragment [4 x 16] + D per rank block -- the canonical fmaf chain
+    // (smi_common.h lora_fma4) in the accumulators' own register layout, one dword load per operand and lane
+    const bool lora_mfma = p.up_sq == 1 && p.up_sn == p.lora_r && (p.lora_r & 3) == 0 && p.lora_r <= 16 &&
+                           (p.lora_seg == 0 || p.lora_seg % BN == 0);
+    const int nblk = p.lora_r >> 2;
+    const int xoff_t = p.lora_seg ? (bn0 / p.lora_seg) * p.lora_r : 0;  // (lora_mfma: the whole tile is one segment)
     auto epilogue_pair = [&](auto Uc) {
       constexpr int u = decltype(Uc)::value;
       const int n = bn0 + wc * 160 + u * 32 + fq * 8;
@@ -284,9 +304,24 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) bv[j] = to_f(b.e[j]);
       }
+      // MFMA A operand: lane (i = lane & 15, k = lane >> 4) holds up[column of fragment row i][4 blk + k]; fragment row i
+      // of the pair's MFMA nip is output column 8 (i >> 2) + 4 nip + (i & 3) of the pair's 32
+      float au[2][4];
+#pragma unroll
+      for (int nip = 0; nip < 2; ++nip)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) au[nip][b] = 0.f;
+      if (lora_tile && lora_mfma) {
+        const int ncol = bn0 + wc * 160 + u * 32 + 8 * (fr >> 2) + (fr & 3);
+#pragma unroll
+        for (int nip = 0; nip < 2; ++nip)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (b < nblk) au[nip][b] = p.lora_up[(int64_t)(ncol + 4 * nip) * p.lora_r + 4 * b + fq];
+      }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const int m = bm0 + wr * 64 + mi * 16 + fr;
+        const int m = row_of(mi);
         float vv[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -306,43 +341,51 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) vv[j] += to_f(b.e[j]);
         }
-        if (p.lora_r > 0 && m >= p.lora_row0) {
-          const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
-          const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
-          if (p.up_sq == 1 && p.up_sn == p.lora_r && (p.lora_r & 3) == 0) {
-            float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int r0 = 0; r0 < p.lora_r; r0 += 4) {
-              const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + r0);
+        if (lora_tile && (!mix || mi == 3)) {  // (wave-uniform)
+          const bool on = m >= p.lora_row0;
+          if (lora_mfma) {
+            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
+            const float* xr = p.lora_xa + (int64_t)(on ? m - p.lora_row0 : 0) * p.ld_xa + xoff_t + fq;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * p.lora_r + r0);
-                d[j] += xv[0] * uv[0] + xv[1] * uv[1] + xv[2] * uv[2] + xv[3] * uv[3];
+            for (int b = 0; b < 4; ++b)
+              if (b < nblk) {
+                const float bx = on ? xr[4 * b] : 0.f;  // B operand: lane (k = lane >> 4, j = lane & 15) holds xa[row j][4 blk + k]
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[0][b], bx, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[1][b], bx, d1, 0, 0, 0);
               }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) vv[j] += d[j] * p.lora_scale;
-          } else if (p.up_sn == 1 && (p.up_sq & 3) == 0) {
-            float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int r = 0; r < p.lora_r; ++r) {
-              const float xq = xrow[r];
-              const float* ar = p.lora_up + (int64_t)r * p.up_sq + n;
-              const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+            if (on) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                d[j] += xq * a0[j];
-                d[4 + j] += xq * a1[j];
+                vv[j] = __builtin_fmaf(d0[j], p.lora_scale, vv[j]);
+                vv[4 + j] = __builtin_fmaf(d1[j], p.lora_scale, vv[4 + j]);
               }
             }
+          } else if (on) {
+            const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
+            if (p.up_sn == 1 && (p.up_sq & 3) == 0) {  // dX form: "up" is lora_down [r, K] read along K
+              const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
+              float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              for (int r = 0; r < p.lora_r; ++r) {
+                const float xq = xrow[r];
+                const float* ar = p.lora_up + (int64_t)r * p.up_sq + n;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vv[j] += d[j] * p.lora_scale;
-          } else {
+                for (int j = 0; j < 4; ++j) {
+                  d[j] = __builtin_fmaf(xq, a0[j], d[j]);
+                  d[4 + j] = __builtin_fmaf(xq, a1[j], d[4 + j]);
+                }
+              }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
-              const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
-              float d = 0.f;
-              for (int r = 0; r < p.lora_r; ++r) d += xr[r] * up[r * p.up_sq];
-              vv[j] += d * p.lora_scale;
+              for (int j = 0; j < 8; ++j) vv[j] = __builtin_fmaf(d[j], p.lora_scale, vv[j]);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
+                const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
+                float d = 0.f;
+                for (int r = 0; r < p.lora_r; ++r) d = __builtin_fmaf(xr[r], up[r * p.up_sq], d);
+                vv[j] = __builtin_fmaf(d, p.lora_scale, vv[j]);
+              }
             }
           }
         }

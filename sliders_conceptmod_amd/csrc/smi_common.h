@@ -117,6 +117,18 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return 0.5f * (1.f + erf_as(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
 
+// Canonical arithmetic of the LoRA delta in every GEMM epilogue: ONE sequential fp32 FMA chain over the rank index
+// (ascending, from zero), then one FMA with the scale onto the running value.  Written with explicit fmaf so that the
+// result does not depend on how hipcc contracts / vectorises a sum of products in a given kernel, and because this is
+// exactly what v_mfma_f32_16x16x4_f32 computes (a k-ordered fmaf chain, cdna guide section 3) -- a VALU epilogue and an
+// MFMA epilogue give the same bits.
+__device__ __forceinline__ float lora_fma4(float d, f32x4 x, f32x4 u) {
+  d = __builtin_fmaf(x[0], u[0], d);
+  d = __builtin_fmaf(x[1], u[1], d);
+  d = __builtin_fmaf(x[2], u[2], d);
+  return __builtin_fmaf(x[3], u[3], d);
+}
+
 // host side ------------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define SMI_CHECK(cond, ...)            \

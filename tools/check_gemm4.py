@@ -65,6 +65,48 @@ def child(arm):
                 out[f"{code}:{M}x{N}x{K}:e{epi}"] = [err, dig, us]
                 print(f"[{arm}] {str(dt):15s} {M}x{N}x{K} epi={epi}: err {err:.2e}  {us:8.1f} us  "
                       f"{2*M*N*K/us/1e6:7.1f} TF/s", flush=True)
+    # batched-pass form: LoRA delta on the last quarter of the rows only (gemm4's interleaved "mix" tiles), plain and
+    # fused-segment (q|k|v) epilogues, rank 4 and 8
+    for (M, N, K, seg, r) in [(1024, 640, 256, 0, 4), (16384, 1280, 1280, 0, 4), (16384, 3840, 1280, 1280, 4),
+                              (65536, 1920, 640, 640, 8), (65536, 640, 640, 0, 4)]:
+        dt, code = torch.float16, 0
+        g = torch.Generator(device="cuda").manual_seed(M + N + K + r)
+        row0 = 3 * M // 4
+        nseg = N // seg if seg else 1
+        a = torch.randn(M, K, device="cuda", generator=g).to(dt)
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dt)
+        bias = torch.randn(N, device="cuda", generator=g).to(dt)
+        res = torch.randn(M, N, device="cuda", generator=g).to(dt)
+        xa = torch.randn(M - row0, nseg * r, device="cuda", generator=g)
+        up = torch.randn(N, r, device="cuda", generator=g)
+        ref = a.float() @ w.float().t() + bias.float() + res.float()
+        for sg in range(nseg):
+            cs = N // nseg
+            ref[row0:, sg * cs:(sg + 1) * cs] += 0.5 * (xa[:, sg * r:(sg + 1) * r] @ up[sg * cs:(sg + 1) * cs].t())
+        first, err = None, 0.0
+        for rep in range(6):
+            c = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+            rc = lib.smi_op_gemm_rows(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up), r, 0.5, row0, seg,
+                                      None)
+            assert rc == 0, _native.last_error()
+            torch.cuda.synchronize()
+            if first is None:
+                first = c.clone()
+                err = float((c.float() - ref).abs().max() / ref.abs().max())
+            elif not torch.equal(c, first):
+                err = float("inf")
+                break
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            lib.smi_op_gemm_rows(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up), r, 0.5, row0, seg, None)
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) * 100
+        dig = hashlib.sha256(first.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+        out[f"{code}:{M}x{N}x{K}:rows{seg}r{r}"] = [err, dig, us]
+        print(f"[{arm}] rows-form {M}x{N}x{K} seg={seg} r={r}: err {err:.2e}  {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s",
+              flush=True)
     json.dump(out, open(f"gpurun_out/check_gemm4_{arm}.json", "w"))
 
 
