@@ -50,7 +50,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 #define SMI_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <typename T>
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page4[256];  // zero-initialised (conv padding source)
+
+// CONV = implicit-GEMM 3x3 / stride 1 / pad 1 (as gemm3.hip): K runs over (tap, channel); an A row is an output pixel,
+// its source for a K-tile is the pixel's own address + a wave-uniform tap offset, or the zero page when the tap falls
+// outside the image (one 9-bit mask per lane and A unit, for the current and for the next output tile).
+template <typename T, bool CONV>
 __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   typedef typename TT<T>::v8 v8;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -88,15 +93,16 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   // slider step) takes every tile as 192 frozen + 64 adapted rows -- A unit u (= wave row u) is 48 frozen rows + 16
   // adapted ones, so each wave's fourth m-fragment is the adapted one and the delta's epilogue cost is spread evenly
   // over all tiles and waves instead of quadrupling the epilogue of a quarter of the tiles (the launch waits for those).
-  const bool mix = p.lora_r > 0 && p.lora_row0 > 0 && 4 * (int64_t)p.lora_row0 == 3 * (int64_t)p.M;
+  const bool mix = !CONV && p.lora_r > 0 && p.lora_row0 > 0 && 4 * (int64_t)p.lora_row0 == 3 * (int64_t)p.M;
+  const int lda = CONV ? p.Cin : (int)p.lda;  // elements between consecutive A rows (conv: NHWC pixels are contiguous)
   const bool arow = mix && wave >= 6;  // this wave stages the adapted rows of a unit (wave-uniform)
-  const uint32_t voffA = (uint32_t)(arow ? r64 - 48 : r64) * (uint32_t)(p.lda * 2) + chunk * 16;
+  const uint32_t voffA = (uint32_t)(arow ? r64 - 48 : r64) * (uint32_t)(lda * 2) + chunk * 16;
   // B unit u, LDS row r = 32 wc' + 16 nip + fr  <-  W row (output column) 160 wc' + 32 u + 8 (fr >> 2) + 4 nip + (fr & 3):
   // after the two MFMAs of a pair a lane owns 8 consecutive output columns
   const uint32_t voffB =
       (uint32_t)((r64 >> 5) * 160 + 8 * ((r64 & 15) >> 2) + 4 * ((r64 >> 4) & 1) + (r64 & 3)) * (uint32_t)(p.K * 2) +
       chunk * 16;
-  const int64_t a_unit = (int64_t)(mix ? (arow ? 16 : 48) : 64) * p.lda * 2;  // bytes between this wave's rows of A units
+  const int64_t a_unit = (int64_t)(mix ? (arow ? 16 : 48) : 64) * lda * 2;  // bytes between this wave's rows of A units
   const int64_t w_unit = (int64_t)32 * p.K * 2;    // bytes between B units (32 output columns)
   const int ldsw = wave * 1024;                    // this wave's slice of a unit
 
@@ -106,16 +112,52 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   tile_origin(v, bm0, bn0);
   // first row this wave stages for tile origin bm: plain bm; mix: frozen block 3/4 bm or adapted block row0 + bm/4
   auto a_row0 = [&](int bm) { return mix ? (arow ? p.lora_row0 + (bm >> 2) : 3 * (bm >> 2)) : bm; };
-  const char* a_cur = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm0) * p.lda * 2;
+  const char* a_cur = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm0) * lda * 2;
   const char* w_cur = reinterpret_cast<const char*>(p.W) + (int64_t)bn0 * p.K * 2;
   const char* a_nxt = a_cur;
   const char* w_nxt = w_cur;
   bool has_next = false;
 
+  // conv: bit (3 ky + kx) of am[u] is set when that tap of the lane's pixel of unit u lies inside the image
+  int am_cur[4] = {0, 0, 0, 0}, am_nxt[4] = {0, 0, 0, 0};
+  auto conv_masks = [&](int bm, int (&am)[4]) {
+    const int hw = p.Hin * p.Win;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = bm + u * 64 + r64;
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int oy = rem / p.Win, ox = rem - oy * p.Win;
+      int mk = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bool ok = (unsigned)(oy + ky - 1) < (unsigned)p.Hin && (unsigned)(ox + kx - 1) < (unsigned)p.Win;
+          mk |= ok ? (1 << (3 * ky + kx)) : 0;
+        }
+      am[u] = mk;
+    }
+  };
+  if (CONV) conv_masks(bm0, am_cur);
+  const int cpt = CONV ? p.Cin / BK : 1;         // K-tiles per filter tap
+  const int cpt_magic = 65536 / cpt + 1;         // tap = (kt * magic) >> 16, exact for kt < 9 * cpt <= 65536 / 9
+
   // stage unit u of K-tile tp (counted from the current output tile's first; tp >= nk runs into the next tile)
   auto stage_a = [&](int u, int tp, unsigned char* buf) {
-    const char* base = tp < nk ? a_cur + (int64_t)tp * (BK * 2) : a_nxt + (int64_t)(tp - nk) * (BK * 2);
-    glds16(base + u * a_unit + voffA, buf + u * UNIT + ldsw);
+    const bool nx = tp >= nk;
+    const int tt = nx ? tp - nk : tp;
+    if (CONV) {
+      const int tap = (tt * cpt_magic) >> 16;
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      const int64_t toff = ((int64_t)((ky - 1) * p.Win + (kx - 1)) * p.Cin + (tt - tap * cpt) * BK) * 2;
+      const int mk = nx ? am_nxt[u] : am_cur[u];
+      const char* src = (nx ? a_nxt : a_cur) + u * a_unit + toff + voffA;
+      glds16(((mk >> tap) & 1) ? (const void*)src : (const void*)g_zero_page4, buf + u * UNIT + ldsw);
+    } else {
+      const char* base = (nx ? a_nxt : a_cur) + (int64_t)tt * (BK * 2);
+      glds16(base + u * a_unit + voffA, buf + u * UNIT + ldsw);
+    }
   };
   auto stage_b = [&](int u, int tp, unsigned char* buf) {
     const char* base = tp < nk ? w_cur + (int64_t)tp * (BK * 2) : w_nxt + (int64_t)(tp - nk) * (BK * 2);
@@ -189,7 +231,8 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
       has_next = vn < ntiles;
       if (has_next) {
         tile_origin(vn, bm1, bn1);
-        a_nxt = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm1) * p.lda * 2;
+        a_nxt = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm1) * lda * 2;
+        if (CONV) conv_masks(bm1, am_nxt);
         w_nxt = reinterpret_cast<const char*>(p.W) + (int64_t)bn1 * p.K * 2;
       }
     }
@@ -420,19 +463,24 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
     bn0 = bn1;
     a_cur = a_nxt;
     w_cur = w_nxt;
+    if (CONV) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) am_cur[u] = am_nxt[u];
+    }
   }
 }
 
-template <typename T>
+template <typename T, bool CONV>
 int launch_t(const GemmParams& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_5ph_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM4));
+    SMI_HIP(hipFuncSetAttribute((const void*)gemm_5ph_kernel<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SMEM4));
     attr_done = true;
   }
   const int ntiles = (p.M / BM) * (p.N / BN);
   const int grid = ntiles < 256 ? ntiles : 256;
-  hipLaunchKernelGGL((gemm_5ph_kernel<T>), dim3(grid), dim3(512), SMEM4, stream, p);
+  hipLaunchKernelGGL((gemm_5ph_kernel<T, CONV>), dim3(grid), dim3(512), SMEM4, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -441,20 +489,24 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 
 bool gemm2_supported(const GemmParams& p);
 
-// dense GEMMs on whole 256 x 320 tiles
+// dense GEMMs and plain 3x3 convs on whole 256 x 320 tiles
 bool gemm4_supported(const GemmParams& p) {
   if (!gemm2_supported(p)) return false;
-  if (p.conv || p.geglu_out) return false;
+  if (p.geglu_out) return false;
+  if (p.conv && (p.stride != 1 || p.pad != 1 || p.upsample || p.transposed || p.Cin % BK != 0 || p.Hout != p.Hin ||
+                 p.Wout != p.Win || p.K != 9 * p.Cin || p.M != p.Nb * p.Hout * p.Wout))
+    return false;
   if (p.M % BM != 0 || p.N % BN != 0 || p.K % BK != 0 || p.K < 2 * BK) return false;
   if (p.lora_seg % 8 != 0) return false;
   if (p.out_f32 && p.ldc % 4 != 0) return false;
-  if ((int64_t)BM * p.lda * 2 >= (1ll << 31) || (int64_t)BN * p.K * 2 >= (1ll << 31)) return false;  // 32-bit lane offsets
+  const int64_t lda = p.conv ? p.Cin : p.lda;
+  if ((int64_t)BM * lda * 2 >= (1ll << 31) || (int64_t)BN * p.K * 2 >= (1ll << 31)) return false;  // 32-bit lane offsets
   return true;
 }
 
 int launch_gemm4(const GemmParams& p, hipStream_t stream) {
-  if (p.dtype == DT_F16) return launch_t<f16>(p, stream);
-  return launch_t<bf16>(p, stream);
+  if (p.dtype == DT_F16) return p.conv ? launch_t<f16, true>(p, stream) : launch_t<f16, false>(p, stream);
+  return p.conv ? launch_t<bf16, true>(p, stream) : launch_t<bf16, false>(p, stream);
 }
 
 }  // namespace smi

@@ -107,6 +107,44 @@ def child(arm):
         out[f"{code}:{M}x{N}x{K}:rows{seg}r{r}"] = [err, dig, us]
         print(f"[{arm}] rows-form {M}x{N}x{K} seg={seg} r={r}: err {err:.2e}  {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s",
               flush=True)
+    # implicit-GEMM 3x3 convs (NHWC activations, [Cout, 9 Cin] tap-major filters): image borders, several images per tile
+    for (nb, H, W, Cin, Cout) in [(4, 16, 16, 64, 320), (3, 32, 64, 128, 640), (16, 128, 128, 320, 320),
+                                  (16, 64, 64, 640, 640), (16, 32, 32, 1280, 1280), (16, 64, 64, 1920, 640),
+                                  (16, 128, 128, 960, 320), (16, 32, 32, 2560, 1280), (16, 64, 64, 320, 640)]:
+        for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
+            if code == 1 and Cin > 640:
+                continue
+            g = torch.Generator(device="cuda").manual_seed(nb + H + Cin + Cout)
+            x = torch.randn(nb, H, W, Cin, device="cuda", generator=g).to(dt)
+            w = (torch.randn(Cout, 9 * Cin, device="cuda", generator=g) * (9 * Cin) ** -0.5).to(dt)
+            b = torch.randn(Cout, device="cuda", generator=g).to(dt)
+            ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2),
+                                             w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b.float(),
+                                             padding=1).permute(0, 2, 3, 1)
+            first, err = None, 0.0
+            for rep in range(5):
+                y = torch.full((nb, H, W, Cout), float("nan"), device="cuda", dtype=dt)
+                rc = lib.smi_op_conv3x3(code, P(x), P(w), P(b), P(y), nb, H, W, Cin, Cout, 1, 0, 0, H, W, None)
+                assert rc == 0, _native.last_error()
+                torch.cuda.synchronize()
+                if first is None:
+                    first = y.clone()
+                    err = float((y.float() - ref).abs().max() / ref.abs().max())
+                elif not torch.equal(y, first):
+                    err = float("inf")
+                    break
+            del ref
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                lib.smi_op_conv3x3(code, P(x), P(w), P(b), P(y), nb, H, W, Cin, Cout, 1, 0, 0, H, W, None)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 100
+            dig = hashlib.sha256(first.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+            out[f"{code}:conv{nb}x{H}x{W}x{Cin}->{Cout}"] = [err, dig, us]
+            print(f"[{arm}] conv {nb}x{H}x{W} {Cin}->{Cout} dt={code}: err {err:.2e}  {us:8.1f} us  "
+                  f"{2*nb*H*W*Cout*9*Cin/us/1e6:7.1f} TF/s", flush=True)
     json.dump(out, open(f"gpurun_out/check_gemm4_{arm}.json", "w"))
 
 
@@ -126,7 +164,7 @@ if __name__ == "__main__":
     for k in a:
         ea, da, ta = a[k]
         eb, db, tb = b[k]
-        tol = 2e-3 if k.startswith("0:") else 1.2e-2
+        tol = 2.5e-3 if k.startswith("0:") else 1.5e-2
         ok = ea < tol and eb < tol and da == db
         bad += 0 if ok else 1
         print(f"{k:28s} base {ta:8.1f} us  v4 {tb:8.1f} us  x{ta/tb:5.2f}  err {ea:.1e}/{eb:.1e}  "
