@@ -55,8 +55,12 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page4[256];  // ze
 // CONV = implicit-GEMM 3x3 / stride 1 / pad 1 (as gemm3.hip): K runs over (tap, channel); an A row is an output pixel,
 // its source for a K-tile is the pixel's own address + a wave-uniform tap offset, or the zero page when the tap falls
 // outside the image (one 9-bit mask per lane and A unit, for the current and for the next output tile).
-template <typename T, bool CONV>
+// MODE: 0 dense, 1 conv, 2 dense with the fused GEGLU epilogue (separate instantiations: each keeps only its own epilogue,
+// which is what keeps the 160 accumulators + epilogue temporaries inside 256 registers)
+template <typename T, int MODE>
 __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
+  constexpr bool CONV = MODE == 1;
+  constexpr bool GEGLU = MODE == 2;
   typedef typename TT<T>::v8 v8;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -99,11 +103,18 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   const uint32_t voffA = (uint32_t)(arow ? r64 - 48 : r64) * (uint32_t)(lda * 2) + chunk * 16;
   // B unit u, LDS row r = 32 wc' + 16 nip + fr  <-  W row (output column) 160 wc' + 32 u + 8 (fr >> 2) + 4 nip + (fr & 3):
   // after the two MFMAs of a pair a lane owns 8 consecutive output columns
+  // fused GEGLU (N = 2 x N_half, tile = 160 hidden columns + their 160 gate columns): the pair's first MFMA takes 16
+  // hidden columns, the second the SAME 16 gate columns, so a lane ends up with hidden and gate of 4 consecutive
+  // columns of one row and forms hidden * gelu(gate) in registers:  row r  <-  W row (nip ? N_half : 0) + 80 wc' + 16 u + fr
+  constexpr bool geglu = GEGLU;
+  const int nhalf = p.N >> 1;
   const uint32_t voffB =
-      (uint32_t)((r64 >> 5) * 160 + 8 * ((r64 & 15) >> 2) + 4 * ((r64 >> 4) & 1) + (r64 & 3)) * (uint32_t)(p.K * 2) +
+      (geglu ? (uint32_t)(((r64 >> 4) & 1) * nhalf + (r64 >> 5) * 80 + (r64 & 15))
+             : (uint32_t)((r64 >> 5) * 160 + 8 * ((r64 & 15) >> 2) + 4 * ((r64 >> 4) & 1) + (r64 & 3))) *
+          (uint32_t)(p.K * 2) +
       chunk * 16;
   const int64_t a_unit = (int64_t)(mix ? (arow ? 16 : 48) : 64) * lda * 2;  // bytes between this wave's rows of A units
-  const int64_t w_unit = (int64_t)32 * p.K * 2;    // bytes between B units (32 output columns)
+  const int64_t w_unit = (int64_t)(geglu ? 16 : 32) * p.K * 2;  // bytes between B units (32 output columns)
   const int ldsw = wave * 1024;                    // this wave's slice of a unit
 
   // output tile state (wave-uniform)
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   // first row this wave stages for tile origin bm: plain bm; mix: frozen block 3/4 bm or adapted block row0 + bm/4
   auto a_row0 = [&](int bm) { return mix ? (arow ? p.lora_row0 + (bm >> 2) : 3 * (bm >> 2)) : bm; };
   const char* a_cur = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm0) * lda * 2;
-  const char* w_cur = reinterpret_cast<const char*>(p.W) + (int64_t)bn0 * p.K * 2;
+  const char* w_cur = reinterpret_cast<const char*>(p.W) + (int64_t)(geglu ? bn0 >> 1 : bn0) * p.K * 2;
   const char* a_nxt = a_cur;
   const char* w_nxt = w_cur;
   bool has_next = false;
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
         tile_origin(vn, bm1, bn1);
         a_nxt = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm1) * lda * 2;
         if (CONV) conv_masks(bm1, am_nxt);
-        w_nxt = reinterpret_cast<const char*>(p.W) + (int64_t)bn1 * p.K * 2;
+        w_nxt = reinterpret_cast<const char*>(p.W) + (int64_t)(geglu ? bn1 >> 1 : bn1) * p.K * 2;
       }
     }
     for (int t = 0; t < nk; ++t, ++gk) {
@@ -450,11 +461,61 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
         }
       }
     };
-    epilogue_pair(std::integral_constant<int, 0>{});
-    epilogue_pair(std::integral_constant<int, 1>{});
-    epilogue_pair(std::integral_constant<int, 2>{});
-    epilogue_pair(std::integral_constant<int, 3>{});
-    epilogue_pair(std::integral_constant<int, 4>{});
+    // fused GEGLU (bias only; same arithmetic as gemm2 / gemm3: the projection is rounded to 16 bits first, the gate is
+    // applied to the rounded values): 8-byte stores of 4 consecutive columns
+    auto epilogue_geglu = [&](auto Uc) {
+      constexpr int u = decltype(Uc)::value;
+      const int hc = (bn0 >> 1) + wc * 80 + u * 16 + fq * 4;  // hidden column; its gate is column nhalf + hc
+      float bh[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        Pack4<T> b0, b1;
+        b0.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.bias) + hc);
+        b1.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.bias) + nhalf + hc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = to_f(b0.e[j]);
+          bg[j] = to_f(b1.e[j]);
+        }
+      }
+      T* gout = reinterpret_cast<T*>(p.geglu_out);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = bm0 + wr * 64 + mi * 16 + fr;
+        Pack4<T> h, g, o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float vh = acc[2 * u][mi][j], vg = acc[2 * u + 1][mi][j];
+          acc[2 * u][mi][j] = 0.f;
+          acc[2 * u + 1][mi][j] = 0.f;
+          if (p.bias) {
+            vh += bh[j];
+            vg += bg[j];
+          }
+          h.e[j] = from_f<T>(vh);
+          g.e[j] = from_f<T>(vg);
+          o.e[j] = from_f<T>(to_f(h.e[j]) * gelu_f(to_f(g.e[j])));
+        }
+        *reinterpret_cast<u32x2*>(gout + (int64_t)m * nhalf + hc) = o.u;
+        if (m >= p.geglu_row0) {  // projection kept only for the rows that will be differentiated
+          T* cp = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc;
+          *reinterpret_cast<u32x2*>(cp + hc) = h.u;
+          *reinterpret_cast<u32x2*>(cp + nhalf + hc) = g.u;
+        }
+      }
+    };
+    if constexpr (GEGLU) {
+      epilogue_geglu(std::integral_constant<int, 0>{});
+      epilogue_geglu(std::integral_constant<int, 1>{});
+      epilogue_geglu(std::integral_constant<int, 2>{});
+      epilogue_geglu(std::integral_constant<int, 3>{});
+      epilogue_geglu(std::integral_constant<int, 4>{});
+    } else {
+      epilogue_pair(std::integral_constant<int, 0>{});
+      epilogue_pair(std::integral_constant<int, 1>{});
+      epilogue_pair(std::integral_constant<int, 2>{});
+      epilogue_pair(std::integral_constant<int, 3>{});
+      epilogue_pair(std::integral_constant<int, 4>{});
+    }
     SMI_FENCE();
     if (!has_next) break;
     if (grp == 1) __builtin_amdgcn_s_barrier();  // re-stagger
@@ -470,17 +531,17 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   }
 }
 
-template <typename T, bool CONV>
+template <typename T, int MODE>
 int launch_t(const GemmParams& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_5ph_kernel<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SMI_HIP(hipFuncSetAttribute((const void*)gemm_5ph_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SMEM4));
     attr_done = true;
   }
   const int ntiles = (p.M / BM) * (p.N / BN);
   const int grid = ntiles < 256 ? ntiles : 256;
-  hipLaunchKernelGGL((gemm_5ph_kernel<T, CONV>), dim3(grid), dim3(512), SMEM4, stream, p);
+  hipLaunchKernelGGL((gemm_5ph_kernel<T, MODE>), dim3(grid), dim3(512), SMEM4, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -492,7 +553,9 @@ bool gemm2_supported(const GemmParams& p);
 // dense GEMMs and plain 3x3 convs on whole 256 x 320 tiles
 bool gemm4_supported(const GemmParams& p) {
   if (!gemm2_supported(p)) return false;
-  if (p.geglu_out) return false;
+  if (p.geglu_out && (p.conv || p.out_f32 || p.res || p.rowvec || p.lora_r > 0 ||
+                      (reinterpret_cast<uintptr_t>(p.geglu_out) & 15) != 0))
+    return false;
   if (p.conv && (p.stride != 1 || p.pad != 1 || p.upsample || p.transposed || p.Cin % BK != 0 || p.Hout != p.Hin ||
                  p.Wout != p.Win || p.K != 9 * p.Cin || p.M != p.Nb * p.Hout * p.Wout))
     return false;
@@ -505,8 +568,10 @@ bool gemm4_supported(const GemmParams& p) {
 }
 
 int launch_gemm4(const GemmParams& p, hipStream_t stream) {
-  if (p.dtype == DT_F16) return p.conv ? launch_t<f16, true>(p, stream) : launch_t<f16, false>(p, stream);
-  return p.conv ? launch_t<bf16, true>(p, stream) : launch_t<bf16, false>(p, stream);
+  const int mode = p.conv ? 1 : (p.geglu_out ? 2 : 0);
+  if (p.dtype == DT_F16)
+    return mode == 1 ? launch_t<f16, 1>(p, stream) : (mode == 2 ? launch_t<f16, 2>(p, stream) : launch_t<f16, 0>(p, stream));
+  return mode == 1 ? launch_t<bf16, 1>(p, stream) : (mode == 2 ? launch_t<bf16, 2>(p, stream) : launch_t<bf16, 0>(p, stream));
 }
 
 }  // namespace smi

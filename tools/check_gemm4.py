@@ -43,7 +43,7 @@ def child(arm):
                     c = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
                     rc = lib.smi_op_gemm(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up),
                                          4 if epi == 2 else 0, 0.5 if epi == 2 else 0.0, 0, None)
-                    assert rc == 0, _native.last_error()
+                    assert rc == 0, lib.smi_last_error()
                     torch.cuda.synchronize()
                     if first is None:
                         first = c.clone()
@@ -88,7 +88,7 @@ def child(arm):
             c = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
             rc = lib.smi_op_gemm_rows(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up), r, 0.5, row0, seg,
                                       None)
-            assert rc == 0, _native.last_error()
+            assert rc == 0, lib.smi_last_error()
             torch.cuda.synchronize()
             if first is None:
                 first = c.clone()
@@ -107,6 +107,45 @@ def child(arm):
         out[f"{code}:{M}x{N}x{K}:rows{seg}r{r}"] = [err, dig, us]
         print(f"[{arm}] rows-form {M}x{N}x{K} seg={seg} r={r}: err {err:.2e}  {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s",
               flush=True)
+    # fused GEGLU: out = proj[:, :N/2] * gelu(proj[:, N/2:]), projection kept for the rows >= row0
+    for (M, N, K) in [(256, 1280, 128), (1024, 2560, 320), (16384, 10240, 1280), (65536, 5120, 640)]:
+        for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
+            g = torch.Generator(device="cuda").manual_seed(M + N + K)
+            row0 = 3 * M // 4
+            a = torch.randn(M, K, device="cuda", generator=g).to(dt)
+            w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dt)
+            bias = torch.randn(N, device="cuda", generator=g).to(dt)
+            pr = (a.float() @ w.float().t() + bias.float()).to(dt).float()
+            ref = pr[:, :N // 2] * torch.nn.functional.gelu(pr[:, N // 2:])
+            first, err = None, 0.0
+            for rep in range(5):
+                o = torch.full((M, N // 2), float("nan"), device="cuda", dtype=dt)
+                pj = torch.zeros(M, N, device="cuda", dtype=dt)
+                rc = lib.smi_op_gemm_geglu(code, P(a), P(w), P(bias), P(o), P(pj), M, N, K, row0, None)
+                assert rc == 0, lib.smi_last_error()
+                torch.cuda.synchronize()
+                both = torch.cat([o, pj[row0:].reshape(-1, N // 2)], 0)
+                if first is None:
+                    first = both.clone()
+                    err = float((o.float() - ref).abs().max() / ref.abs().max())
+                    err = max(err, float((pj[row0:].float() - pr[row0:]).abs().max() / pr.abs().max()))
+                    if float(pj[:row0].abs().max()) != 0.0:
+                        err = float("inf")  # frozen rows of the projection must not be written
+                elif not torch.equal(both, first):
+                    err = float("inf")
+                    break
+            del ref, pr
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                lib.smi_op_gemm_geglu(code, P(a), P(w), P(bias), P(o), P(pj), M, N, K, row0, None)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 100
+            dig = hashlib.sha256(first.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+            out[f"{code}:geglu{M}x{N}x{K}"] = [err, dig, us]
+            print(f"[{arm}] geglu {M}x{N}x{K} dt={code}: err {err:.2e}  {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s",
+                  flush=True)
     # implicit-GEMM 3x3 convs (NHWC activations, [Cout, 9 Cin] tap-major filters): image borders, several images per tile
     for (nb, H, W, Cin, Cout) in [(4, 16, 16, 64, 320), (3, 32, 64, 128, 640), (16, 128, 128, 320, 320),
                                   (16, 64, 64, 640, 640), (16, 32, 32, 1280, 1280), (16, 64, 64, 1920, 640),
@@ -125,7 +164,7 @@ def child(arm):
             for rep in range(5):
                 y = torch.full((nb, H, W, Cout), float("nan"), device="cuda", dtype=dt)
                 rc = lib.smi_op_conv3x3(code, P(x), P(w), P(b), P(y), nb, H, W, Cin, Cout, 1, 0, 0, H, W, None)
-                assert rc == 0, _native.last_error()
+                assert rc == 0, lib.smi_last_error()
                 torch.cuda.synchronize()
                 if first is None:
                     first = y.clone()
@@ -164,7 +203,7 @@ if __name__ == "__main__":
     for k in a:
         ea, da, ta = a[k]
         eb, db, tb = b[k]
-        tol = 2.5e-3 if k.startswith("0:") else 1.5e-2
+        tol = 4e-3 if k.startswith("0:") else 2.5e-2
         ok = ea < tol and eb < tol and da == db
         bad += 0 if ok else 1
         print(f"{k:28s} base {ta:8.1f} us  v4 {tb:8.1f} us  x{ta/tb:5.2f}  err {ea:.1e}/{eb:.1e}  "
