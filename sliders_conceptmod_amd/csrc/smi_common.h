@@ -112,7 +112,20 @@ __device__ __forceinline__ float erf_as(float x) {
   const float r = 1.f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f)); }
+// gelu(x) = x Phi(x) with Phi from the same A&S 7.1.26 erf, folded so that the sign needs no copysign / select:
+//   x >= 0: x (1 - q),  x < 0: x q,  q = 0.5 poly(t) exp(-x^2 / 2)   ==   max(x, 0) - |x| q
+// (14 VALU operations, v_rcp + v_exp among them; the bare v_exp_f32 is enough -- where its result would be subnormal q
+// is far below the rounding of x).  This sits in the epilogue of the largest GEMM of the step (ff.net.0: 80 gates per lane
+// and 256 x 320 tile), which is pure VALU time the MFMAs wait for.
+__device__ __forceinline__ float gelu_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.f));
+  const float poly =
+      t * (0.5f * 0.254829592f +
+           t * (0.5f * -0.284496736f + t * (0.5f * 1.421413741f + t * (0.5f * -1.453152027f + t * (0.5f * 1.061405429f)))));
+  const float q = poly * __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+  return __builtin_fmaf(-ax, q, fmaxf(x, 0.f));
+}
 __device__ __forceinline__ float dgelu_f(float x) {
   return 0.5f * (1.f + erf_as(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }

@@ -338,15 +338,16 @@ def test_step_ops_match_torch(lib):
 def test_gemm_generations_are_bit_identical_per_epilogue_class():
     """The tile autotuner (csrc/gemm.hip) may serve a (shape, epilogue) key with any kernel generation / tile layout;
     that is only sound while they all produce the SAME BITS.  One op per key class -- full LoRA epilogue (bias + residual
-    + rank-r delta), fp32 output, fused GEGLU, 3x3 conv -- hashed in separate processes under every SMI_GEMM override
-    (ADVICE r1)."""
+    + rank-r delta, also in the batched-pass form with the delta on the last quarter of the rows), fp32 output, fused
+    GEGLU, 3x3 conv -- hashed in separate processes under every SMI_GEMM override.  "5ph" is the 256 x 320
+    persistent kernel (gemm4.hip): its delta comes off the fp32 MFMA and must equal the VALU fmaf chain of the others."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("128", "256", "160", "64", "8ph", ""):
+    for mode in ("128", "256", "160", "64", "8ph", "5ph", ""):
         env = dict(os.environ)
         env.pop("SMI_GEMM", None)
         if mode:
@@ -360,3 +361,18 @@ def test_gemm_generations_are_bit_identical_per_epilogue_class():
     for mode, d in res.items():
         diff = [k for k in base if d[k] != base[k]]
         assert not diff, f"SMI_GEMM={mode} differs from the 128x128 kernel on {diff}"
+
+
+def test_gemm4_persistent_256x320_kernel_screen():
+    """gemm4.hip (256 x 320 persistent tile, LDS-DMA pipeline running across output tiles, fp32-MFMA LoRA delta,
+    interleaved frozen / adapted rows, in-register GEGLU, implicit-GEMM conv) forced with SMI_GEMM=5ph in a child process:
+    every case is compared with fp32 torch, bit-for-bit with the heuristic selection of the older generations, and
+    bit-for-bit with its own repeated runs (race screen of the counted-vmcnt schedule) -- tools/check_gemm4.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_gemm4.py")], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    tail = "\n".join(l for l in r.stdout.splitlines() if not l.startswith("["))[-3000:]
+    assert r.returncode == 0 and "ALL OK" in r.stdout, tail + r.stderr[-1500:]

@@ -38,6 +38,16 @@ def main():
             c32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
             _native.check(lib.smi_op_gemm(code, P(a), P(w), P(c32), M, N, K, P(bias), None, None, None, 0, 0.0, 1, None), "gemm")
             out[f"{tag}/f32_out/{M}x{N}x{K}"] = dig(c32)
+        # batched-pass form (delta on the last quarter of the rows; gemm4 interleaves frozen / adapted rows per tile)
+        for M, N, K, r, seg in ((16384, 1280, 1280, 4, 0), (16384, 3840, 1280, 4, 1280), (4096, 1920, 640, 8, 640)):
+            a, w = rn(M, K).to(dt), rn(N, K, sc=K ** -0.5).to(dt)
+            bias, res = rn(N).to(dt), rn(M, N).to(dt)
+            row0 = 3 * M // 4
+            xa, up = rn(M - row0, r * (N // seg if seg else 1)), rn(N, r)
+            c = torch.empty(M, N, device="cuda", dtype=dt)
+            _native.check(lib.smi_op_gemm_rows(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up), r, 0.25,
+                                               row0, seg, None), "gemm_rows")
+            out[f"{tag}/lora_rows/{M}x{N}x{K}r{r}s{seg}"] = dig(c)
         for M, N, K in ((16384, 10240, 1280), (4096, 5120, 640)):
             a, w, bias = rn(M, K).to(dt), rn(N, K, sc=K ** -0.5).to(dt), rn(N).to(dt)
             o = torch.empty(M, N // 2, device="cuda", dtype=dt)
