@@ -13,6 +13,7 @@
 // row m = (image, oy, ox), K index = (ky, kx, ci).  Cin % 64 == 0 keeps every 64-wide K step inside one filter tap,
 // so the tap geometry is wave-uniform scalar work; padding, tails and strided/transposed/up-sampled taps turn
 // into out-of-range buffer offsets, which the hardware range check returns as zeros.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <unordered_map>
@@ -414,6 +415,8 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
       return 0;
     }
     float tbest = 0.f, t0 = 0.f;
+    static const bool dump = getenv("SMI_TUNE_DUMP") != nullptr;  // candidate timings of every tuned key on stderr
+    if (dump) fprintf(stderr, "[smi tune]");
     for (int i = 0; i < nc; ++i) {
       if (launch_candidate(q, cands[i], stream) != 0) continue;  // warm-up (also sets the LDS attribute once)
       (void)hipEventRecord(a, stream);
@@ -423,9 +426,13 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
       if (hipEventSynchronize(b) != hipSuccess) break;
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, a, b);
+      if (dump) fprintf(stderr, " %d:%.1fus", cands[i], ms * 500.f);
       if (i == 0) { t0 = tbest = ms; continue; }
       if (ms < 0.97f * t0 && ms < tbest) { tbest = ms; best = cands[i]; }
     }
+    if (dump)
+      fprintf(stderr, "  -> %d   [%s M=%d N=%d K=%d%s%s%s%s]\n", best, p.conv ? "conv" : "gemm", p.M, p.N, p.K,
+              p.bias ? " bias" : "", p.res ? " res" : "", p.lora_r ? " lora" : "", p.geglu_out ? " geglu" : "");
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     if (tmp) {
