@@ -13,7 +13,7 @@ supplied directly, resident in HBM before the timed region.  Weights are random-
 (no checkpoints offline) -- "data": "synthetic".
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel class (the MFMA GEMM kernels gemm_glds_kernel / gemm_8ph_kernel: Linear + implicit-GEMM conv launches), algorithmic
+  roofline     -- dominant kernel class (the MFMA GEMM kernels gemm_5ph_kernel / gemm_8ph_kernel / gemm_glds_kernel: Linear + implicit-GEMM conv launches), algorithmic
                   FLOPs / device time measured with HIP events on the launch stream in a separate profiled step
   cpu_baseline -- the CPU oracle (oracle/unet_ref.py, kind "port") timed on this box's host cores on a bounded sample
 """
@@ -44,7 +44,7 @@ def pmc_traffic(config):
     if not paths:
         return None
     path = paths[-1]  # the latest round's passes (file names sort by round tag)
-    rows = [v for k, v in json.load(open(path)).items() if "gemm_glds_kernel" in k or "gemm_8ph_kernel" in k]
+    rows = [v for k, v in json.load(open(path)).items() if "gemm_glds_kernel" in k or "gemm_8ph_kernel" in k or "gemm_5ph_kernel" in k]
     n = sum(v["launches"] for v in rows)
     return (sum(v["total_fetch_bytes"] + v["total_write_bytes"] for v in rows) / n) if n else None
 
@@ -422,7 +422,7 @@ def main():
             "step_algorithmic_tflop": step_flops / 1e12,
             "step_tflops_achieved": step_flops / 1e12 / (ms_per_step * 1e-3),
             "step_frac_of_mfma_peak": step_flops / 1e12 / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS,
-            "roofline": {"kernel": "gemm_glds_kernel + gemm_8ph_kernel (Linear GEMMs + implicit-GEMM 3x3 convs)",
+            "roofline": {"kernel": "gemm_5ph_kernel + gemm_8ph_kernel + gemm_glds_kernel (Linear GEMMs + implicit-GEMM 3x3 convs)",
                          "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(args.config),
