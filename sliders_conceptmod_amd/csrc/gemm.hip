@@ -393,6 +393,8 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
     if (gemm3_supported(p) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) cands[nc++] = 100;
     if (!p.conv && (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) <= 512) cands[nc++] = 7;  // 64 x 128 tiles for small grids
     if (gemm4_supported(p) && (int64_t)(p.M / 256) * (p.N / 320) >= 128) cands[nc++] = 200;
+  } else if (p.conv && p.upsample && gemm4_supported(p) && (int64_t)(p.M / 256) * (p.N / 320) >= 128) {
+    cands[nc++] = 200;  // up-sampler convs: gemm2's general gather or gemm4's row-aligned one
   }
   int best = 0;
   if (nc > 1) {

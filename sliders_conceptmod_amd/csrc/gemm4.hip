@@ -55,12 +55,14 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page4[256];  // ze
 // CONV = implicit-GEMM 3x3 / stride 1 / pad 1 (as gemm3.hip): K runs over (tap, channel); an A row is an output pixel,
 // its source for a K-tile is the pixel's own address + a wave-uniform tap offset, or the zero page when the tap falls
 // outside the image (one 9-bit mask per lane and A unit, for the current and for the next output tile).
-// MODE: 0 dense, 1 conv, 2 dense with the fused GEGLU epilogue (separate instantiations: each keeps only its own epilogue,
+// MODE: 0 dense, 1 conv, 2 dense with the fused GEGLU epilogue, 3 conv with the 2x up-sampling folded into the gather
+// (separate instantiations: each keeps only its own epilogue,
 // which is what keeps the 160 accumulators + epilogue temporaries inside 256 registers)
 template <typename T, int MODE>
 __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   constexpr bool CONV = MODE == 1;
   constexpr bool GEGLU = MODE == 2;
+  constexpr bool UPS = MODE == 3;  // 3x3 conv on the nearest-2x up-sampled input (the UNet's up-samplers), Wout % 64 == 0
   typedef typename TT<T>::v8 v8;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   // adapted ones, so each wave's fourth m-fragment is the adapted one and the delta's epilogue cost is spread evenly
   // over all tiles and waves instead of quadrupling the epilogue of a quarter of the tiles (the launch waits for those).
   const bool mix = !CONV && p.lora_r > 0 && p.lora_row0 > 0 && 4 * (int64_t)p.lora_row0 == 3 * (int64_t)p.M;
-  const int lda = CONV ? p.Cin : (int)p.lda;  // elements between consecutive A rows (conv: NHWC pixels are contiguous)
+  const int lda = (CONV || UPS) ? p.Cin : (int)p.lda;  // elements between consecutive A rows (conv: NHWC pixels are contiguous)
   const bool arow = mix && wave >= 6;  // this wave stages the adapted rows of a unit (wave-uniform)
   const uint32_t voffA = (uint32_t)(arow ? r64 - 48 : r64) * (uint32_t)(lda * 2) + chunk * 16;
   // B unit u, LDS row r = 32 wc' + 16 nip + fr  <-  W row (output column) 160 wc' + 32 u + 8 (fr >> 2) + 4 nip + (fr & 3):
@@ -151,14 +153,50 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
     }
   };
   if (CONV) conv_masks(bm0, am_cur);
-  const int cpt = CONV ? p.Cin / BK : 1;         // K-tiles per filter tap
+  const int cpt = (CONV || UPS) ? p.Cin / BK : 1;  // K-tiles per filter tap
   const int cpt_magic = 65536 / cpt + 1;         // tap = (kt * magic) >> 16, exact for kt < 9 * cpt <= 65536 / 9
+
+  // UPS: a unit is 64 consecutive output pixels of ONE output row (Wout % 64 == 0), so the row, the image and the first
+  // column are wave-uniform per unit and only the column is per lane: input column = (ox0 + r + kx - 1) >> 1, i.e. the
+  // lane offsets depend on kx alone (three constants) and the horizontal border test is two VALU operations.
+  int ub_cur[4] = {0, 0, 0, 0}, uy_cur[4] = {0, 0, 0, 0}, ux_cur[4] = {0, 0, 0, 0};
+  int ub_nxt[4] = {0, 0, 0, 0}, uy_nxt[4] = {0, 0, 0, 0}, ux_nxt[4] = {0, 0, 0, 0};
+  auto ups_units = [&](int bm, int (&ub)[4], int (&uy)[4], int (&ux)[4]) {
+    const int hw = p.Hout * p.Wout;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m0 = bm + u * 64;
+      const int img = m0 / hw;
+      const int rem = m0 - img * hw;
+      const int oy = rem / p.Wout;
+      ub[u] = __builtin_amdgcn_readfirstlane(img * p.Hin * p.Win);
+      uy[u] = __builtin_amdgcn_readfirstlane(oy);
+      ux[u] = __builtin_amdgcn_readfirstlane(rem - oy * p.Wout);
+    }
+  };
+  int voffU[3] = {0, 0, 0};
+  if (UPS) {
+    ups_units(bm0, ub_cur, uy_cur, ux_cur);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) voffU[kx] = ((r64 + kx - 1) >> 1) * (p.Cin * 2) + chunk * 16;
+  }
 
   // stage unit u of K-tile tp (counted from the current output tile's first; tp >= nk runs into the next tile)
   auto stage_a = [&](int u, int tp, unsigned char* buf) {
     const bool nx = tp >= nk;
     const int tt = nx ? tp - nk : tp;
-    if (CONV) {
+    if (UPS) {
+      const int tap = (tt * cpt_magic) >> 16;
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      const int oy = nx ? uy_nxt[u] : uy_cur[u], ox0 = nx ? ux_nxt[u] : ux_cur[u], ub = nx ? ub_nxt[u] : ub_cur[u];
+      const int iy2 = oy + ky - 1;
+      const bool vok = (unsigned)iy2 < (unsigned)(2 * p.Hin);
+      const char* base = reinterpret_cast<const char*>(p.A) +
+                         ((int64_t)(ub + (iy2 >> 1) * p.Win + (ox0 >> 1)) * p.Cin + (tt - tap * cpt) * BK) * 2;
+      const int vo = kx == 0 ? voffU[0] : (kx == 1 ? voffU[1] : voffU[2]);
+      const bool ok = vok && (unsigned)(ox0 + r64 + kx - 1) < (unsigned)(2 * p.Win);
+      glds16(ok ? (const void*)(base + vo) : (const void*)g_zero_page4, buf + u * UNIT + ldsw);
+    } else if (CONV) {
       const int tap = (tt * cpt_magic) >> 16;
       const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
       const int64_t toff = ((int64_t)((ky - 1) * p.Win + (kx - 1)) * p.Cin + (tt - tap * cpt) * BK) * 2;
@@ -244,6 +282,7 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
         tile_origin(vn, bm1, bn1);
         a_nxt = reinterpret_cast<const char*>(p.A) + (int64_t)a_row0(bm1) * lda * 2;
         if (CONV) conv_masks(bm1, am_nxt);
+        if (UPS) ups_units(bm1, ub_nxt, uy_nxt, ux_nxt);
         w_nxt = reinterpret_cast<const char*>(p.W) + (int64_t)(geglu ? bn1 >> 1 : bn1) * p.K * 2;
       }
     }
@@ -528,6 +567,14 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) am_cur[u] = am_nxt[u];
     }
+    if (UPS) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ub_cur[u] = ub_nxt[u];
+        uy_cur[u] = uy_nxt[u];
+        ux_cur[u] = ux_nxt[u];
+      }
+    }
   }
 }
 
@@ -556,9 +603,11 @@ bool gemm4_supported(const GemmParams& p) {
   if (p.geglu_out && (p.conv || p.out_f32 || p.res || p.rowvec || p.lora_r > 0 ||
                       (reinterpret_cast<uintptr_t>(p.geglu_out) & 15) != 0))
     return false;
-  if (p.conv && (p.stride != 1 || p.pad != 1 || p.upsample || p.transposed || p.Cin % BK != 0 || p.Hout != p.Hin ||
-                 p.Wout != p.Win || p.K != 9 * p.Cin || p.M != p.Nb * p.Hout * p.Wout))
+  if (p.conv && (p.stride != 1 || p.pad != 1 || p.transposed || p.Cin % BK != 0 || p.K != 9 * p.Cin ||
+                 p.M != p.Nb * p.Hout * p.Wout))
     return false;
+  if (p.conv && !p.upsample && (p.Hout != p.Hin || p.Wout != p.Win)) return false;
+  if (p.conv && p.upsample && (p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win || p.Wout % 64 != 0)) return false;
   if (p.M % BM != 0 || p.N % BN != 0 || p.K % BK != 0 || p.K < 2 * BK) return false;
   if (p.lora_seg % 8 != 0) return false;
   if (p.out_f32 && p.ldc % 4 != 0) return false;
@@ -568,10 +617,16 @@ bool gemm4_supported(const GemmParams& p) {
 }
 
 int launch_gemm4(const GemmParams& p, hipStream_t stream) {
-  const int mode = p.conv ? 1 : (p.geglu_out ? 2 : 0);
+  const int mode = p.conv ? (p.upsample ? 3 : 1) : (p.geglu_out ? 2 : 0);
   if (p.dtype == DT_F16)
-    return mode == 1 ? launch_t<f16, 1>(p, stream) : (mode == 2 ? launch_t<f16, 2>(p, stream) : launch_t<f16, 0>(p, stream));
-  return mode == 1 ? launch_t<bf16, 1>(p, stream) : (mode == 2 ? launch_t<bf16, 2>(p, stream) : launch_t<bf16, 0>(p, stream));
+    return mode == 1   ? launch_t<f16, 1>(p, stream)
+           : mode == 2 ? launch_t<f16, 2>(p, stream)
+           : mode == 3 ? launch_t<f16, 3>(p, stream)
+                       : launch_t<f16, 0>(p, stream);
+  return mode == 1   ? launch_t<bf16, 1>(p, stream)
+         : mode == 2 ? launch_t<bf16, 2>(p, stream)
+         : mode == 3 ? launch_t<bf16, 3>(p, stream)
+                     : launch_t<bf16, 0>(p, stream);
 }
 
 }  // namespace smi

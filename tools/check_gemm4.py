@@ -184,6 +184,44 @@ def child(arm):
             out[f"{code}:conv{nb}x{H}x{W}x{Cin}->{Cout}"] = [err, dig, us]
             print(f"[{arm}] conv {nb}x{H}x{W} {Cin}->{Cout} dt={code}: err {err:.2e}  {us:8.1f} us  "
                   f"{2*nb*H*W*Cout*9*Cin/us/1e6:7.1f} TF/s", flush=True)
+    # up-sampler convs: nearest-2x up-sampling folded into the gather (Wout % 64 == 0 on gemm4)
+    for (nb, H, W, Cin, Cout) in [(2, 32, 32, 64, 320), (1, 32, 64, 128, 640), (16, 64, 64, 640, 640),
+                                  (16, 32, 32, 1280, 1280)]:
+        for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
+            if code == 1 and Cin > 640:
+                continue
+            g = torch.Generator(device="cuda").manual_seed(nb + H + Cin + Cout + 1)
+            x = torch.randn(nb, H, W, Cin, device="cuda", generator=g).to(dt)
+            w = (torch.randn(Cout, 9 * Cin, device="cuda", generator=g) * (9 * Cin) ** -0.5).to(dt)
+            b = torch.randn(Cout, device="cuda", generator=g).to(dt)
+            xu = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+            ref = torch.nn.functional.conv2d(xu, w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b.float(),
+                                             padding=1).permute(0, 2, 3, 1)
+            del xu
+            first, err = None, 0.0
+            for rep in range(5):
+                y = torch.full((nb, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=dt)
+                rc = lib.smi_op_conv3x3(code, P(x), P(w), P(b), P(y), nb, H, W, Cin, Cout, 1, 1, 0, 2 * H, 2 * W, None)
+                assert rc == 0, lib.smi_last_error()
+                torch.cuda.synchronize()
+                if first is None:
+                    first = y.clone()
+                    err = float((y.float() - ref).abs().max() / ref.abs().max())
+                elif not torch.equal(y, first):
+                    err = float("inf")
+                    break
+            del ref
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                lib.smi_op_conv3x3(code, P(x), P(w), P(b), P(y), nb, H, W, Cin, Cout, 1, 1, 0, 2 * H, 2 * W, None)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 100
+            dig = hashlib.sha256(first.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+            out[f"{code}:upconv{nb}x{H}x{W}x{Cin}->{Cout}"] = [err, dig, us]
+            print(f"[{arm}] upconv {nb}x{H}x{W} {Cin}->{Cout} dt={code}: err {err:.2e}  {us:8.1f} us  "
+                  f"{2*nb*4*H*W*Cout*9*Cin/us/1e6:7.1f} TF/s", flush=True)
     json.dump(out, open(f"gpurun_out/check_gemm4_{arm}.json", "w"))
 
 
