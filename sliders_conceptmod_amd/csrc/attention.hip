@@ -115,7 +115,10 @@ __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r 
 // =============================================================================================================
 // forward
 // =============================================================================================================
-template <typename T, int DP>
+// EX: head_dim == DP (SD-XL: 64).  The number of 16-wide k-steps is then a compile-time constant -- with the run-time
+// `s < nsd` test hipcc wraps every (ds_read, MFMA) pair of the QK^T product in its own branch and waits lgkmcnt(0) after
+// each read: eight exposed LDS round trips per key tile and wave instead of eight reads in flight.
+template <typename T, int DP, bool EX>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   xcd_block(bx, head, b);
   const int q_idx = bx * 128 + wave * 32 + ql;
   const int col0 = head * p.D;
-  const int nsd = (p.D + 15) / 16;
+  const int nsd = EX ? DP / 16 : (p.D + 15) / 16;
 
   const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
   const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
@@ -287,7 +290,7 @@ __global__ void attn_delta_kernel(AttnParams p) {
 //   S^T = K Q^T ; P^T = exp(scale*S^T - lse[q]) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta[q])
 //   dQ^T[d,q] += K^T[d,keys] dS^T[keys,q]
 // =============================================================================================================
-template <typename T, int DP>
+template <typename T, int DP, bool EX>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   xcd_block(bx, head, b);
   const int q_idx = bx * 128 + wave * 32 + ql;
   const int col0 = head * p.D;
-  const int nsd = (p.D + 15) / 16;
+  const int nsd = EX ? DP / 16 : (p.D + 15) / 16;
 
   const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
   const auto rG = make_rsrc((const T*)p.dO + (int64_t)b * p.Nq * p.lddo, (uint32_t)((int64_t)p.Nq * p.lddo * 2));
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 //   dV^T[d,key] += dO^T[d,q] P[q,key] ;  dK^T[d,key] += Q^T[d,q] dS[q,key]
 // WHICH: 1 = dK only, 2 = dV only, 3 = both (register budget: both only fits for DP <= 96)
 // =============================================================================================================
-template <typename T, int DP, int WHICH>
+template <typename T, int DP, int WHICH, bool EX>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   xcd_block(bx, head, b);
   const int k_idx = bx * 128 + wave * 32 + kl;
   const int col0 = head * p.D;
-  const int nsd = (p.D + 15) / 16;
+  const int nsd = EX ? DP / 16 : (p.D + 15) / 16;
 
   const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
   const auto rG = make_rsrc((const T*)p.dO + (int64_t)b * p.Nq * p.lddo, (uint32_t)((int64_t)p.Nq * p.lddo * 2));
@@ -576,7 +579,10 @@ int check_attn(const AttnParams& p) {
 template <typename T, int DP>
 int fwd_t(const AttnParams& p, hipStream_t st) {
   dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, DP>), grid, dim3(256), 0, st, p);
+  if (p.D == DP)
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, false>), grid, dim3(256), 0, st, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -590,31 +596,49 @@ int bwd_t(const AttnParams& p, hipStream_t st) {
   }
   if (p.dQ) {
     dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP>), grid, dim3(256), 0, st, p);
+    if (p.D == DP)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, true>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, false>), grid, dim3(256), 0, st, p);
   }
   if (p.dK || p.dV) {
     SMI_CHECK(p.dK && p.dV, "attention bwd: dK and dV must both be given");
     dim3 grid(cdiv(p.Nk, 128), p.H, p.B);
     const size_t sm = dkv_smem<T, DP>();
+    const bool ex = p.D == DP;
     if (DP <= 96) {
       static bool attr_set = false;
       if (!attr_set && sm > 65536) {
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 3>,
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 3, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 3, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         attr_set = true;
       }
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 3>), grid, dim3(256), sm, st, p);
+      if (ex)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 3, true>), grid, dim3(256), sm, st, p);
+      else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 3, false>), grid, dim3(256), sm, st, p);
     } else {
       static bool attr_set = false;
       if (!attr_set) {
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 1>,
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 1, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 2>,
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 2, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 1, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 2, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         attr_set = true;
       }
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 1>), grid, dim3(256), sm, st, p);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 2>), grid, dim3(256), sm, st, p);
+      if (ex) {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 1, true>), grid, dim3(256), sm, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 2, true>), grid, dim3(256), sm, st, p);
+      } else {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 1, false>), grid, dim3(256), sm, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 2, false>), grid, dim3(256), sm, st, p);
+      }
     }
   }
   SMI_HIP(hipGetLastError());
