@@ -13,6 +13,9 @@ SHAPES = [(256, 320, 128), (256, 320, 192), (512, 640, 320), (16384, 1280, 1280)
           (16384, 640, 5120), (16384, 5120, 1280), (65536, 320, 960), (16384, 10240, 1280), (4096, 1280, 10240)]
 
 
+QUICK = os.environ.get("SMI_CHECK_QUICK") == "1"  # the pytest screen: every mode and epilogue class, fewer big shapes / repeats
+
+
 def child(arm):
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,8 +23,12 @@ def child(arm):
     lib = _native.lib()
     P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     out = {}
+    shapes = [sh for sh in SHAPES if not QUICK or sh in ((256, 320, 128), (512, 640, 320), (16384, 1280, 1280),
+                                                        (16384, 3840, 1280), (65536, 640, 640), (4096, 1280, 1280))]
     for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
-        for (M, N, K) in SHAPES:
+        for (M, N, K) in shapes:
+            if QUICK and code == 1 and M * N * K > 1e10:
+                continue
             for epi in (0, 1, 2):  # 0: plain, 1: bias + res, 2: bias + res + LoRA rank 4 on the rows >= M/2? (all rows)
                 if dt == torch.bfloat16 and epi == 2:
                     continue
@@ -38,7 +45,7 @@ def child(arm):
                 if epi == 2:
                     ref = ref + 0.5 * (xa @ up.t())
                 first = None
-                nrep = 12 if M * N * K < 2e11 else 5
+                nrep = (12 if M * N * K < 2e11 else 5) if not QUICK else 4
                 for rep in range(nrep):
                     c = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
                     rc = lib.smi_op_gemm(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up),
@@ -109,7 +116,11 @@ def child(arm):
               flush=True)
     # fused GEGLU: out = proj[:, :N/2] * gelu(proj[:, N/2:]), projection kept for the rows >= row0
     for (M, N, K) in [(256, 1280, 128), (1024, 2560, 320), (16384, 10240, 1280), (65536, 5120, 640)]:
+        if QUICK and M == 65536:
+            continue
         for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
+            if QUICK and code == 1 and M > 1024:
+                continue
             g = torch.Generator(device="cuda").manual_seed(M + N + K)
             row0 = 3 * M // 4
             a = torch.randn(M, K, device="cuda", generator=g).to(dt)
@@ -150,8 +161,10 @@ def child(arm):
     for (nb, H, W, Cin, Cout) in [(4, 16, 16, 64, 320), (3, 32, 64, 128, 640), (16, 128, 128, 320, 320),
                                   (16, 64, 64, 640, 640), (16, 32, 32, 1280, 1280), (16, 64, 64, 1920, 640),
                                   (16, 128, 128, 960, 320), (16, 32, 32, 2560, 1280), (16, 64, 64, 320, 640)]:
+        if QUICK and nb * H * W * Cout * Cin > 16 * 64 * 64 * 640 * 640:
+            continue
         for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
-            if code == 1 and Cin > 640:
+            if code == 1 and (Cin > 640 or (QUICK and nb * H * W > 4096)):
                 continue
             g = torch.Generator(device="cuda").manual_seed(nb + H + Cin + Cout)
             x = torch.randn(nb, H, W, Cin, device="cuda", generator=g).to(dt)
@@ -187,8 +200,10 @@ def child(arm):
     # up-sampler convs: nearest-2x up-sampling folded into the gather (Wout % 64 == 0 on gemm4)
     for (nb, H, W, Cin, Cout) in [(2, 32, 32, 64, 320), (1, 32, 64, 128, 640), (16, 64, 64, 640, 640),
                                   (16, 32, 32, 1280, 1280)]:
+        if QUICK and Cin > 640:
+            continue
         for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
-            if code == 1 and Cin > 640:
+            if code == 1 and (Cin > 640 or (QUICK and nb > 2)):
                 continue
             g = torch.Generator(device="cuda").manual_seed(nb + H + Cin + Cout + 1)
             x = torch.randn(nb, H, W, Cin, device="cuda", generator=g).to(dt)
