@@ -307,7 +307,7 @@ static int gemm_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SMI_GEMM");
-    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : (!strcmp(e, "64w") ? 11 : (!strcmp(e, "5ph") ? 12 : (!strcmp(e, "no5ph") ? 13 : 0)))))))))))));
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : (!strcmp(e, "64w") ? 11 : (!strcmp(e, "5ph") ? 12 : (!strcmp(e, "no5ph") ? 13 : (!strcmp(e, "160w") ? 14 : 0))))))))))))));
   }
   return mode;
 }
@@ -383,7 +383,7 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
   auto& cache = tune_cache();
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
-  int cands[8], nc = 0;
+  int cands[10], nc = 0;
   cands[nc++] = 0;
   const bool plain_conv = p.conv && p.stride == 1 && !p.upsample && !p.transposed;
   if (!p.conv || plain_conv) {
@@ -393,6 +393,8 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
     if (gemm3_supported(p) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) cands[nc++] = 100;
     if (!p.conv && (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) <= 512) cands[nc++] = 7;  // 64 x 128 tiles for small grids
     if (gemm4_supported(p) && (int64_t)(p.M / 256) * (p.N / 320) >= 128) cands[nc++] = 200;
+    // about one 128 x 160 tile per CU: the eight-wave form of that tile
+    if (!p.geglu_out && p.N % 160 == 0 && p.N % 8 == 0 && (int64_t)cdiv(p.M, 128) * (p.N / 160) <= 512) cands[nc++] = 10;
   } else if (p.conv && p.upsample && gemm4_supported(p) && (int64_t)(p.M / 256) * (p.N / 320) >= 128) {
     cands[nc++] = 200;  // up-sampler convs: gemm2's general gather or gemm4's row-aligned one
   }
@@ -462,6 +464,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   // v3 (256x256 tile, 8-phase schedule): SMI_GEMM=8ph forces it wherever its layout rules hold, =no8ph disables it
   // v4 (256x320 tile, persistent): SMI_GEMM=5ph forces it wherever its layout rules hold
   if (gemm_mode() == 12 && gemm4_supported(p)) return launch_gemm4(p, stream);
+  if (gemm_mode() == 14 && gemm2_supported(p) && !p.geglu_out && p.N % 160 == 0) return launch_gemm2(p, 10, stream);
   if ((gemm_mode() == 6 || ((gemm_mode() == 0 || gemm_mode() == 10) && gemm3_wanted(p))) && gemm3_supported(p))
     return launch_gemm3(p, stream);
   if (gemm_mode() != 3 && gemm2_supported(p) && (!p.conv || gemm_mode() != 4)) {

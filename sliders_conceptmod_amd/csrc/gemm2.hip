@@ -38,23 +38,31 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // NL = 2: BN = 128 with TWICE the waves (4 WM, as 2 WM (M) x 2 (N), 32 x 64 per wave): for grids of about one
 // workgroup per CU, where a lone wave per SIMD serialises its DMA issue, fragment reads and MFMAs -- two waves per
 // SIMD from the same workgroup overlap them.
+// NL = 3: BN = 160 with twice the waves, as 2 WM (M) x 2 (N), 32 x 80 per wave = FIVE column fragments: two pairs (8
+// consecutive columns per lane, as everywhere) and one single fragment (4 columns per lane; its epilogue is the 4-column
+// path that exists for conv_out).  For N = 1280 at 4096 rows this is 32 x 8 = 256 tiles -- one round of the CUs with
+// two waves per SIMD -- where the 128 x 128 eight-wave tile needs 320 tiles = 1.25 rounds.
 template <typename T, bool CONV, int WM, int NL>
-__global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(GemmParams p) {
-  constexpr int BN = NL == 1 ? 160 : 128;
+__global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(GemmParams p) {
+  constexpr int BN = (NL == 1 || NL == 3) ? 160 : 128;
   constexpr int BM = 64 * WM;
-  constexpr int NW = (NL == 2 ? 4 : 2) * WM;
+  constexpr int NW = (NL >= 2 ? 4 : 2) * WM;
   constexpr int MI = NL ? 2 : 4;          // 16-row fragments per wave
-  constexpr int NI = NL == 1 ? 10 : 4;    // 16-column fragments per wave
-  static_assert(((BN / 8) % NW) == 0, "W tile rows must split evenly over the waves");
+  constexpr int NI = NL == 1 ? 10 : (NL == 3 ? 5 : 4);  // 16-column fragments per wave
+  static_assert(NL == 3 || ((BN / 8) % NW) == 0, "W tile rows must split evenly over the waves");
   constexpr int STAGE = (BM + BN) * BK * 2;  // bytes
   constexpr int A_INSTR = (BM / 8) / NW;     // 1-KiB wave-instructions per wave for the A tile (= 4)
-  constexpr int B_INSTR = (BN / 8) / NW;     // (= 4 or 2)
+  // (NL = 3: 20 B pieces over 8 waves -- piece j * NW + wave, waves 0-3 issue three, waves 4-7 two)
+  constexpr int B_INSTR = (BN / 8 + NW - 1) / NW;  // (= 4, 2 or 3)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = NL == 1 ? wave : wave >> 1, wn = NL == 1 ? 0 : wave & 1;
+  auto b_piece = [&](int j) { return NL == 3 ? j * NW + wave : wave * B_INSTR + j; };
+  auto b_valid = [&](int j) { return NL != 3 || j * NW + wave < BN / 8; };
+
   constexpr int WROWS = 16 * MI, WCOLS = 16 * NI;  // wave tile
 
   const int nbn = (p.N + BN - 1) / BN;
@@ -121,14 +129,22 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
   int w_chunk[B_INSTR];
 #pragma unroll
   for (int j = 0; j < B_INSTR; ++j) {
-    const int row = (wave * B_INSTR + j) * 8 + lrow;
+    const int row = b_piece(j) * 8 + lrow;
     // epilogue lane remap, applied at staging time so fragment reads stay on consecutive (conflict-free) LDS rows:
     // LDS row 16*ni + fr (ni counted over the whole tile) holds W row 32*(ni>>1) + 8*(fr>>2) + 4*(ni&1) + (fr&3);
     // after the MFMAs of the pair (2q, 2q+1) a lane then owns the 8 consecutive columns 32q + 8*fq + {0..7}.
+    // NL = 3 pairs inside each wave column's five fragments; the fifth keeps its columns in order (4 per lane).
     const int ni_ = row >> 4, fr_ = row & 15;
-    const int n = gcol((ni_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (ni_ & 1) + (fr_ & 3));
+    int col;
+    if (NL == 3) {
+      const int wn_ = row / 80, l = row - wn_ * 80, nl_ = l >> 4;
+      col = wn_ * 80 + (nl_ < 4 ? (nl_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (nl_ & 1) + (fr_ & 3) : 64 + (l & 15));
+    } else {
+      col = (ni_ >> 1) * 32 + 8 * (fr_ >> 2) + 4 * (ni_ & 1) + (fr_ & 3);
+    }
+    const int n = gcol(col);
     w_chunk[j] = lslot ^ (row & 7);
-    w_ptr[j] = (n < p.N) ? Wp + (int64_t)n * p.K : nullptr;
+    w_ptr[j] = (b_valid(j) && n < p.N) ? Wp + (int64_t)n * p.K : nullptr;
   }
 
   // dense operands with K % 64 == 0 (every layer of the UNets): the source of each LDS-DMA is a per-lane pointer that
@@ -161,7 +177,7 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
     }
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
-      glds16(w_src[j], Bs + (wave * B_INSTR + j) * 1024);
+      if (b_valid(j)) glds16(w_src[j], Bs + b_piece(j) * 1024);
       w_src[j] += w_step[j];
     }
   };
@@ -224,7 +240,7 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
     for (int j = 0; j < B_INSTR; ++j) {
       const int kc = k0 + w_chunk[j] * 8;
       const void* src = (w_ptr[j] && kc < p.K) ? (const void*)(w_ptr[j] + kc) : (const void*)zero;
-      glds16(src, Bs + (wave * B_INSTR + j) * 1024);
+      if (b_valid(j)) glds16(src, Bs + b_piece(j) * 1024);
     }
   };
 
@@ -306,17 +322,19 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
     const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
     const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
 #pragma unroll
-    for (int q = 0; q < NI / 2; ++q) {
-      const int nl = wn * WCOLS + q * 32 + fq * 8;
+    for (int q = 0; q < (NI + 1) / 2; ++q) {
+      constexpr bool ODD = (NI & 1) != 0;
+      const bool single = ODD && q == NI / 2;  // NL = 3: the wave's fifth fragment, 4 columns per lane
+      const int nl = single ? wn * WCOLS + (NI - 1) * 16 + fq * 4 : wn * WCOLS + q * 32 + fq * 8;
       const int n = gcol(nl);
       if (n >= p.N) continue;
       float v[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         v[j] = acc[2 * q][mi][j];
-        v[4 + j] = acc[2 * q + 1][mi][j];
+        v[4 + j] = acc[(2 * q + 1 < NI) ? 2 * q + 1 : 0][mi][j];  // (unused for the single fragment)
       }
-      const bool full = n + 8 <= p.N;  // N % 8 may be 4 (conv_out): second half masked
+      const bool full = !single && n + 8 <= p.N;  // N % 8 may be 4 (conv_out): second half masked
       if (p.bias) {
         const T* bp = reinterpret_cast<const T*>(p.bias) + n;
         if (full) {
@@ -347,26 +365,30 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
       }
       if (lora_on) {
         const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
-        if (full && p.up_sq == 1 && p.up_sn == p.lora_r && (p.lora_r & 3) == 0) {
+        if ((full || single) && p.up_sq == 1 && p.up_sn == p.lora_r && (p.lora_r & 3) == 0) {
           // forward, rank 4 / 8 / ...: 16-byte loads of xa and of each output column's row of lora_up [N, r]
+          // (the single fragment of the 32 x 80 wave tile: its 4 columns only)
           float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int r0 = 0; r0 < p.lora_r; r0 += 4) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + r0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * p.lora_r + r0);
-              d[j] = lora_fma4(d[j], xv, uv);
+              if (j < 4 || full) {
+                const f32x4 uv = *reinterpret_cast<const f32x4*>(p.lora_up + (int64_t)(n + j) * p.lora_r + r0);
+                d[j] = lora_fma4(d[j], xv, uv);
+              }
             }
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(d[j], p.lora_scale, v[j]);
-        } else if (full && p.up_sn == 1 && (p.up_sq & 3) == 0) {
+        } else if ((full || single) && p.up_sn == 1 && (p.up_sq & 3) == 0) {
           // backward (dX): "up" is lora_down [r_tot, K] read along K: 8 consecutive columns = two 16-byte loads per q
           float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int r = 0; r < p.lora_r; ++r) {
             const float xq = xrow[r];
             const float* ar = p.lora_up + (int64_t)r * p.up_sq + n;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
+            const f32x4 a1 = full ? *reinterpret_cast<const f32x4*>(ar + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               d[j] = __builtin_fmaf(xq, a0[j], d[j]);
@@ -378,7 +400,7 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (n + j < p.N) {
+            if ((full || j < 4) && n + j < p.N) {
               const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
               const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
               float d = 0.f;
@@ -406,11 +428,16 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
         float* op = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
         *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
         if (full) *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else if (stage_out) {
+      } else if (stage_out && full) {
         Pack8<T> o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.e[j] = from_f<T>(v[j]);
         *reinterpret_cast<u32x4*>(otile + ml * OLD + nl) = o.u;
+      } else if (stage_out) {
+        Pack4<T> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.e[j] = from_f<T>(v[j]);
+        *reinterpret_cast<u32x2*>(otile + ml * OLD + nl) = o.u;
       } else {
         T* op = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
         Pack4<T> o;
@@ -473,9 +500,9 @@ __global__ __launch_bounds__((NL == 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
 
 template <typename T, bool CONV, int WM, int NL>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-  constexpr int BN = NL == 1 ? 160 : 128;
+  constexpr int BN = (NL == 1 || NL == 3) ? 160 : 128;
   constexpr int BM = 64 * WM;
-  constexpr int NW = (NL == 2 ? 4 : 2) * WM;
+  constexpr int NW = (NL >= 2 ? 4 : 2) * WM;
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done && SMEM > 65536) {
@@ -544,6 +571,10 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
   if (variant == 4 && ok160) { wm = 2; nl = 1; }
   if (variant == 5) { wm = 2; nl = 2; }
   if (variant == 7 && !p.conv) { wm = 1; nl = 2; }  // 64 x 128 tile, 4 waves of 32 x 64: twice the tiles for small grids
+  if (variant == 10 && ok160 && !p.geglu_out) {  // 128 x 160 tile with eight waves of 32 x 80 (NL = 3)
+    if (p.dtype == DT_F16) return p.conv ? launch_t<f16, true, 2, 3>(p, stream) : launch_t<f16, false, 2, 3>(p, stream);
+    return p.conv ? launch_t<bf16, true, 2, 3>(p, stream) : launch_t<bf16, false, 2, 3>(p, stream);
+  }
 #define GO(TT_, CV, W_, NL_) return launch_t<TT_, CV, W_, NL_>(p, stream)
 #define PICK(TT_, CV)                            \
   do {                                           \

@@ -347,7 +347,7 @@ def test_gemm_generations_are_bit_identical_per_epilogue_class():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("128", "256", "160", "64", "8ph", "5ph", ""):
+    for mode in ("128", "256", "160", "160w", "64", "8ph", "5ph", ""):
         env = dict(os.environ)
         env.pop("SMI_GEMM", None)
         if mode:
