@@ -453,6 +453,27 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
   SMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   SMI_CHECK(!p.geglu_out || gemm_geglu_supported(p), "gemm: fused GEGLU not available for this shape/layout");
+  // One 128 x 160 tile per CU with a long K (the 4096-row backward GEMMs and convs): the eight-wave tile with the
+  // four-stage deep-prefetch loop, by RULE and not by tuning -- the tuner times candidates back to back with their
+  // operands hot in L2 / the Infinity Cache, where prefetch depth buys nothing (121 vs 120 us at 4096 x 1280 x 10240);
+  // inside the backward pass the operands come from HBM and the deep form wins (153 -> 129 us, conv K = 11520:
+  // 193 -> 160 us; measured in the step, A/B on one device).  Bit-identical to every other form.  SMI_GEMM_DEEP=0 turns
+  // the rule off, SMI_GEMM_DEEP_K moves the K threshold.
+  if (gemm_mode() == 0) {
+    static int deep = -1, deep_k = 1280;
+    if (deep < 0) {
+      const char* e = getenv("SMI_GEMM_DEEP");
+      deep = (e && !strcmp(e, "0")) ? 0 : 1;
+      if (const char* k = getenv("SMI_GEMM_DEEP_K")) deep_k = atoi(k);
+    }
+    if (deep && gemm2_supported(p) && !p.geglu_out && p.N % 160 == 0 && p.K >= deep_k &&
+        (int64_t)cdiv(p.M, 128) * (p.N / 160) <= 320 && (!p.conv || (p.stride == 1 && !p.upsample && !p.transposed))) {
+      if (p.conv) {
+        SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout, "conv: inconsistent geometry");
+      }
+      return launch_gemm2(p, 11, stream);
+    }
+  }
   if (gemm_mode() == 0 && tune_enabled() && gemm2_supported(p) && (int64_t)p.M * p.N >= (1 << 20)) {
     if (p.conv) {
       SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),

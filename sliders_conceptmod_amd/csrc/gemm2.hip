@@ -42,7 +42,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // consecutive columns per lane, as everywhere) and one single fragment (4 columns per lane; its epilogue is the 4-column
 // path that exists for conv_out).  For N = 1280 at 4096 rows this is 32 x 8 = 256 tiles -- one round of the CUs with
 // two waves per SIMD -- where the 128 x 128 eight-wave tile needs 320 tiles = 1.25 rounds.
-template <typename T, bool CONV, int WM, int NL>
+// DEEP: four LDS stages, three K-tiles of DMA in flight across raw barriers with a counted vmcnt (bit-identical: same K
+// order).  In isolation (operands hot in L2 / the Infinity Cache, which is also what the tile tuner sees) it buys
+// nothing; the question is the cold operands of the real backward pass.
+template <typename T, bool CONV, int WM, int NL, bool DEEP = false>
 __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(GemmParams p) {
   constexpr int BN = (NL == 1 || NL == 3) ? 160 : 128;
   constexpr int BM = 64 * WM;
@@ -273,11 +276,36 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
 
   // (A 4-stage variant -- three tiles in flight across raw barriers, counted vmcnt, one workgroup per CU -- was built
   // and measured for the small grids: 4096 x 1280 x 1280 24-36 us against 22.8 us here.  Not kept.)
-  stage(0, 0);
-  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  // DMA instructions this wave issues per K-tile (NL = 3: waves 4-7 one B piece fewer)
+  const int per = A_INSTR + (NL == 3 ? (wave < (BN / 8) % NW ? B_INSTR : B_INSTR - 1) : B_INSTR);
+  // wait until at most n of this wave's staged K-tiles are still in flight (DEEP only; n = 0, 1, 2)
+  auto wait_tiles = [&](int n) {
+    const int c = n * per;  // wave-uniform; s_waitcnt takes an immediate
+    if (c >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (c == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (c == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (c >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (c == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (DEEP) {
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 2) stage(2, 2);
+    wait_tiles(min(nk, 3) - 1);
+    __builtin_amdgcn_s_barrier();
+  } else {
+    stage(0, 0);
+    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const int buf = DEEP ? (kt & 3) : (kt & 1);
+    if (DEEP) {
+      // buffer (kt + 3) & 3 held K-tile kt - 1: every wave finished reading it before the barrier that ended iteration kt - 1
+      if (kt + 3 < nk) stage(kt + 3, (kt + 3) & 3);
+    } else {
+      if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    }
     const unsigned char* As = smem + buf * STAGE;
     // fragments of both 32-deep halves are fetched up front (two register sets) so the second half's LDS latency
     // hides under the first half's MFMAs
@@ -303,8 +331,15 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = TT<T>::mfma16(wb[kk][ni], xa[kk][mi], acc[ni][mi]);
-    __syncthreads();
+    if (DEEP) {
+      // K-tile kt + 1 must have landed (this wave's pieces; the barrier covers the other waves'): leave kt + 2, kt + 3
+      wait_tiles(min(nk - 1, kt + 3) - (kt + 1));
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
   }
+  if (DEEP) __syncthreads();  // (nothing is in flight any more; the epilogue reuses the staging memory)
 
   // ---- epilogue: per (mi, pair q) the lane holds 8 consecutive columns n = nb + 32q + 8fq + {0..7} of row m.
   // 16-bit results are staged through LDS (free after the last barrier) and written out as whole rows: one wave
@@ -498,20 +533,20 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
   }
 }
 
-template <typename T, bool CONV, int WM, int NL>
+template <typename T, bool CONV, int WM, int NL, bool DEEP = false>
 int launch_t(const GemmParams& p, hipStream_t stream) {
   constexpr int BN = (NL == 1 || NL == 3) ? 160 : 128;
   constexpr int BM = 64 * WM;
   constexpr int NW = (NL >= 2 ? 4 : 2) * WM;
-  constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  constexpr int SMEM = (DEEP ? 4 : 2) * (BM + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done && SMEM > 65536) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, CONV, WM, NL>,
+    SMI_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, CONV, WM, NL, DEEP>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM, NL>), dim3(grid), dim3(NW * 64), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM, NL, DEEP>), dim3(grid), dim3(NW * 64), SMEM, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -571,7 +606,12 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
   if (variant == 4 && ok160) { wm = 2; nl = 1; }
   if (variant == 5) { wm = 2; nl = 2; }
   if (variant == 7 && !p.conv) { wm = 1; nl = 2; }  // 64 x 128 tile, 4 waves of 32 x 64: twice the tiles for small grids
-  if (variant == 10 && ok160 && !p.geglu_out) {  // 128 x 160 tile with eight waves of 32 x 80 (NL = 3)
+  if ((variant == 10 || variant == 11) && ok160 && !p.geglu_out) {  // 128 x 160 tile with eight waves of 32 x 80 (NL = 3)
+    if (variant == 11) {  // ... with the deep-prefetch loop
+      if (p.dtype == DT_F16)
+        return p.conv ? launch_t<f16, true, 2, 3, true>(p, stream) : launch_t<f16, false, 2, 3, true>(p, stream);
+      return p.conv ? launch_t<bf16, true, 2, 3, true>(p, stream) : launch_t<bf16, false, 2, 3, true>(p, stream);
+    }
     if (p.dtype == DT_F16) return p.conv ? launch_t<f16, true, 2, 3>(p, stream) : launch_t<f16, false, 2, 3>(p, stream);
     return p.conv ? launch_t<bf16, true, 2, 3>(p, stream) : launch_t<bf16, false, 2, 3>(p, stream);
   }
