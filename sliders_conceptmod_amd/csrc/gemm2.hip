@@ -348,6 +348,52 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
   constexpr int OLD = BN + 8;  // LDS row length (elements) of the staged output tile: +16 B pad
   const bool stage_out = !p.out_f32 && (p.N % 8 == 0);
   T* otile = reinterpret_cast<T*>(smem);
+
+  // NL = 3 (the tile of the 4096-row backward GEMMs, whose dX carries the rank-r delta on every row): the delta of all
+  // ten (fragment, row-fragment) pairs on the fp32 MFMA, in uniform control flow ahead of the per-lane epilogue --
+  // D[16 cols x 16 rows] = "up"-fragment [16 x 4] * xa-fragment [4 x 16] + D per rank block, the canonical fmaf chain of
+  // smi_common.h in the accumulators' register layout (as in gemm4.hip), for both operand forms (forward: up [N, r];
+  // dX: lora_down [r, K] read along K).  One dword load per operand and lane instead of 3 r 16-byte loads per 8 columns.
+  f32x4 dlt[NL == 3 ? NI : 1][NL == 3 ? MI : 1];
+  bool delta_mfma = false;
+  if constexpr (NL == 3) {
+    const bool fwd_form = p.up_sq == 1 && p.up_sn == p.lora_r;
+    const bool dx_form = p.up_sn == 1 && !fwd_form;
+    delta_mfma = p.lora_r > 0 && (p.lora_r & 3) == 0 && p.lora_r <= 16 && (fwd_form || dx_form) &&
+                 (p.lora_seg == 0 || p.lora_seg % BN == 0) && bm0 + BM > p.lora_row0 && p.N % BN == 0;
+    if (delta_mfma) {
+      const int nblk = p.lora_r >> 2;
+      const int xoff = p.lora_seg ? (bn0 / p.lora_seg) * p.lora_r : 0;
+      float bx[MI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = bm0 + wm * WROWS + mi * 16 + fr;
+        const bool on = m < p.M && m >= p.lora_row0;
+        const float* xr = p.lora_xa + (int64_t)(on ? m - p.lora_row0 : 0) * p.ld_xa + xoff + fq;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bx[mi][b] = (on && b < nblk) ? xr[4 * b] : 0.f;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = bn0 + wn * WCOLS +
+                        (ni < NI - 1 ? (ni >> 1) * 32 + 8 * (fr >> 2) + 4 * (ni & 1) + (fr & 3) : (NI - 1) * 16 + fr);
+        float au[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          au[b] = b < nblk ? (fwd_form ? p.lora_up[(int64_t)col * p.lora_r + 4 * b + fq]
+                                       : p.lora_up[(int64_t)(4 * b + fq) * p.up_sq + col])
+                           : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (b < nblk) d = __builtin_amdgcn_mfma_f32_16x16x4f32(au[b], bx[mi][b], d, 0, 0, 0);
+          dlt[ni][mi] = d;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int ml = wm * WROWS + mi * 16 + fr;
@@ -398,7 +444,17 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
           for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
         }
       }
-      if (lora_on) {
+      if (NL == 3 && delta_mfma) {
+        if (lora_on) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = __builtin_fmaf(dlt[NL == 3 ? 2 * q : 0][NL == 3 ? mi : 0][j], p.lora_scale, v[j]);
+            if (!single)
+              v[4 + j] = __builtin_fmaf(dlt[(NL == 3 && 2 * q + 1 < NI) ? 2 * q + 1 : 0][NL == 3 ? mi : 0][j],
+                                        p.lora_scale, v[4 + j]);
+          }
+        }
+      } else if (lora_on) {
         const float* xrow = xrow0 + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
         if ((full || single) && p.up_sq == 1 && p.up_sn == p.lora_r && (p.lora_r & 3) == 0) {
           // forward, rank 4 / 8 / ...: 16-byte loads of xa and of each output column's row of lora_up [N, r]
