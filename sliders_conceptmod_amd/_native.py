@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmi_hip.so")
+LIB_PATH = os.environ.get("SMI_LIB") or os.path.join(_HERE, "libsmi_hip.so")  # SMI_LIB: A/B runs of tools/ against another build
 SMI_MAX_LEVELS = 8
 DTYPE_CODE = {torch.float16: 0, torch.bfloat16: 1}
 

@@ -13,6 +13,8 @@
 // Backward (activations only: dQ, and dK/dV when a LoRA hangs off to_k/to_v) recomputes P from Q, K and the
 // forward's log-sum-exp; it is split into a dQ kernel (one workgroup per 128 queries, sweeping keys) and a dK/dV
 // kernel (one workgroup per 128 keys, sweeping queries): no atomics, bitwise reproducible.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace smi {
@@ -110,6 +112,50 @@ __device__ __forceinline__ typename TT<T>::v8 ld_frag_trhw(const T* tile, int ld
   u.h[1] = hi;
   return u.v;
 }
+
+// Row sum of eight packed 16-bit probabilities on the matrix pipe: v_mfma_f32_4x4x4 (16 blocks of 4 lanes) with an
+// all-ones A operand gives D[i][j] = sum_k B[k][j], i.e. every lane receives the sum of its OWN four B elements in all
+// four result registers.  Two of them per 8-wide fragment replace eight v_add_f32 of a loop that is VALU-bound, and
+// the normaliser becomes the sum of exactly the rounded values the P.V product consumes.
+template <typename T> struct Sum4;
+template <> struct Sum4<f16> {
+  static __device__ __forceinline__ f32x4 add8(f16x8 pf, f32x4 acc) {
+    const f16x4 one = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+    const f16x4 lo = {pf[0], pf[1], pf[2], pf[3]}, hi = {pf[4], pf[5], pf[6], pf[7]};
+    acc = __builtin_amdgcn_mfma_f32_4x4x4f16(one, lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(one, hi, acc, 0, 0, 0);
+  }
+};
+template <> struct Sum4<bf16> {
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x4 add8(bf16x8 pf, f32x4 acc) {
+    const s4 one = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    union { bf16x8 v; s4 h[2]; } u;
+    u.v = pf;
+    acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one, u.h[0], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one, u.h[1], acc, 0, 0, 0);
+  }
+};
+// Combine a value with the one the lane 32 away holds.  v_permlane32_swap exchanges the upper half of its first operand
+// with the lower half of its second; fed two copies of x it leaves {x.lo in both halves} and {x.hi in both halves}:
+// one VALU instruction and no LDS round trip (__shfl_xor(x, 32) compiles to ds_bpermute_b32).  Inline asm on purpose:
+// with the SAME value in both operands hipcc (ROCm 7.2) treats the builtin's two results as one register
+// (`v_add v1, v1, v1`); the asm's two read-write operands cannot be merged.  s_nop 1: VALU write -> permlane read.
+__device__ __forceinline__ void halves_split(float x, float& lo, float& hi) {
+  lo = x;
+  hi = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ float halves_max(float x) {
+  float a, b;
+  halves_split(x, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float halves_sum(float x) {
+  float a, b;
+  halves_split(x, a, b);
+  return a + b;
+}
 __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
 
 // =============================================================================================================
@@ -152,7 +198,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -INFINITY, l_part = 0.f;
+  float m_run = -INFINITY;
+  f32x4 l4 = {0.f, 0.f, 0.f, 0.f};  // running row sum (all four registers equal), see Sum4
   const float sl = p.scale * LOG2E;
 
   const int ntiles = (p.Nk + TK - 1) / TK;
@@ -172,15 +219,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
 
     f32x16 st[2];
+    if constexpr (EX && NS <= 4) {
+      // all K fragments of the tile in flight before the first MFMA (2 * NS * 4 registers): hipcc otherwise recycles
+      // two fragment registers and waits for every read right in front of the MFMA that consumes it
+      typename TT<T>::v8 kfr[2][NS];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+        for (int s = 0; s < NS; ++s) kfr[sub][s] = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (s < nsd) {
-          const auto kf = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
-          st[sub] = TT<T>::mfma32(kf, qf[s], st[sub]);
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
+      }
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (s < nsd) {
+            const auto kf = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
+            st[sub] = TT<T>::mfma32(kf, qf[s], st[sub]);
+          }
         }
       }
     }
@@ -199,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[sub][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    mloc = halves_max(mloc);
     // Lazy rescale: the running reference m_run only moves when the tile maximum exceeds it by more than 2^8 in the
     // exponent domain; until then probabilities are formed against the stale reference (p <= 256: exact in fp32,
     // representable in fp16 / bf16) and O, l stay un-rescaled.  o / l is unchanged mathematically; it saves the
@@ -209,23 +273,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       const float m_new = need ? mloc : m_run;
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl);  // 1 for lanes that keep their reference
       m_run = m_new;
-      l_part *= alpha;
+      l4 *= alpha;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
-    float psum = 0.f;
     const float mb = m_run * sl;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(st[sub][r] * sl - mb);
-        st[sub][r] = pv;
-        psum += pv;
-      }
-    l_part += psum;
+      for (int r = 0; r < 16; ++r) st[sub][r] = __builtin_amdgcn_exp2f(st[sub][r] * sl - mb);
     // O^T[d, q] += V^T[d, keys] . P^T[keys, q]
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -238,10 +296,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           const auto vf = ld_frag_trhw<T>(Vs, S::LDV, kb, i * 32, lane);
           o[i] = TT<T>::mfma32(vf, pf, o[i]);
         }
+        l4 = Sum4<T>::add8(pf, l4);
       }
   }
 
-  const float l_tot = l_part + __shfl_xor(l_part, 32);
+  const float l_tot = halves_sum(l4[0]);
   const float inv = 1.f / l_tot;
   if (q_idx < p.Nq) {
     T* orow = (T*)p.O + ((int64_t)b * p.Nq + q_idx) * p.ldo + col0;
@@ -290,7 +349,9 @@ __global__ void attn_delta_kernel(AttnParams p) {
 //   S^T = K Q^T ; P^T = exp(scale*S^T - lse[q]) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta[q])
 //   dQ^T[d,q] += K^T[d,keys] dS^T[keys,q]
 // =============================================================================================================
-template <typename T, int DP, bool EX>
+// REMAT: re-broadcast the two row constants in front of every chain (32 v_mov per 32-key sub-tile) instead of keeping
+// two 16-register copies alive across the loop (0 VALU, +32 registers: 2 waves per SIMD instead of 3)
+template <typename T, int DP, bool EX, bool REMAT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
@@ -331,10 +392,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   }
   const bool qok = q_idx < p.Nq;
   const int64_t stat = ((int64_t)b * p.H + head) * p.Nq + (qok ? q_idx : 0);
-  const float lse2 = qok ? p.lse[stat] * LOG2E : INFINITY;
-  const float dlt = dpart + __shfl_xor(dpart, 32);
+  const float dlt = halves_sum(dpart);
   if (qok && h2 == 0) p.delta[stat] = dlt;
   const float sl = p.scale * LOG2E;
+  // Row constants as the INITIAL ACCUMULATORS of the two score products (the query is on the lane, so they are
+  // lane constants): S' = K Q^T - lse / scale leaves its MFMA chain ready for p = exp2(sl * S'), dP' = V dO^T - delta
+  // is the factor of dS -- no zero fill, no subtraction, and no key mask either: rows of K / V past Nk are staged as
+  // zeros, so whatever finite dS they get multiplies a zero row of K.  Padded queries (their Q / dO fragments are
+  // zero) keep both constants at 0.
+  const float cl = qok ? -p.lse[stat] / p.scale : 0.f, cd = qok ? -dlt : 0.f;
+  f32x16 c_lse, c_dlt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    c_lse[r] = cl;
+    c_dlt[r] = cd;
+  }
 
   f32x16 dq[NB];
 #pragma unroll
@@ -359,11 +431,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      f32x16 st, dp;
+      f32x16 st = c_lse, dp = c_dlt;
+      if constexpr (REMAT) {
+        float a = cl, c = cd;
+        asm volatile("" : "+v"(a), "+v"(c));  // opaque per sub-tile: the broadcasts cannot be hoisted out of the loop
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[r] = 0.f;
-        dp[r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          st[r] = a;
+          dp[r] = c;
+        }
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -375,11 +451,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + sub * 32 + acc_row(r, h2);
-        const float pv = (key < p.Nk) ? __builtin_amdgcn_exp2f(st[r] * sl - lse2) : 0.f;
-        st[r] = pv * (dp[r] - dlt);  // dS^T
-      }
+      for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * sl) * dp[r];  // dS^T = P^T o (dP^T - delta)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const auto df = pack8<T>(st, s2);
@@ -425,8 +497,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   T* Gs = Qs + TK * S::LDN;
   T* Qs2 = Gs + TK * S::LDN;  // Q and dO again, at the transposed-read stride
   T* Gs2 = Qs2 + TK * S::LDV;
-  float* lse_s = reinterpret_cast<float*>(Gs2 + TK * S::LDV);
-  float* dlt_s = lse_s + TK;
+  float* lse_s = reinterpret_cast<float*>(Gs2 + TK * S::LDV);  // -lse / scale per staged query (see the dQ kernel)
+  float* dlt_s = lse_s + TK;                                   // -delta
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kl = lane & 31, h2 = lane >> 5;
@@ -452,7 +524,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     kf[s] = t.v;
     vf[s] = u.v;
   }
-  const float sl = p.scale * LOG2E;
+  const float sl = p.scale * LOG2E, inv_scale = 1.f / p.scale;
   const int64_t stat0 = ((int64_t)b * p.H + head) * p.Nq;
 
   f32x16 dk[DO_DK ? NB : 1], dv[DO_DV ? NB : 1];
@@ -473,8 +545,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     S::load(rg, rG, q0, p.Nq, p.lddo, col0, p.D, tid);
     if (tid < TK) {
       const bool ok = q0 + tid < p.Nq;
-      lv = ok ? p.lse[stat0 + q0 + tid] * LOG2E : INFINITY;  // +inf -> P = 0 for padded queries
-      dl = ok ? p.delta[stat0 + q0 + tid] : 0.f;
+      lv = ok ? -p.lse[stat0 + q0 + tid] * inv_scale : 0.f;  // padded queries: their Q / dO rows are zeros, any finite P does
+      dl = ok ? -p.delta[stat0 + q0 + tid] : 0.f;
     }
   };
   fetch(0);
@@ -493,11 +565,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     if (qt + 1 < ntiles) fetch(q0 + TK);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      // the row constants of the four consecutive queries a register quad covers come straight out of LDS as the
+      // initial accumulators: S' = Q K^T - lse / scale, dP' = dO V^T - delta
       f32x16 st, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[r] = 0.f;
-        dp[r] = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 cl = *reinterpret_cast<const f32x4*>(lse_s + sub * 32 + 8 * g + 4 * h2);
+        const f32x4 cd = *reinterpret_cast<const f32x4*>(dlt_s + sub * 32 + 8 * g + 4 * h2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st[4 * g + j] = cl[j];
+          dp[4 * g + j] = DO_DK ? cd[j] : 0.f;
+        }
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -512,10 +591,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int qi = sub * 32 + acc_row(r, h2);
-        const float pv = __builtin_amdgcn_exp2f(st[r] * sl - lse_s[qi]);
-        st[r] = pv;
-        if (DO_DK) dp[r] = pv * (dp[r] - dlt_s[qi]);
+        st[r] = __builtin_amdgcn_exp2f(st[r] * sl);
+        if (DO_DK) dp[r] *= st[r];
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -596,10 +673,13 @@ int bwd_t(const AttnParams& p, hipStream_t st) {
   }
   if (p.dQ) {
     dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
-    if (p.D == DP)
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, true>), grid, dim3(256), 0, st, p);
+    static const bool remat = []() { const char* e = getenv("SMI_ATTN_DQ_REMAT"); return e && e[0] == '1'; }();
+    if (p.D == DP && remat)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, true, true>), grid, dim3(256), 0, st, p);
+    else if (p.D == DP)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, true, false>), grid, dim3(256), 0, st, p);
     else
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, false>), grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, false, true>), grid, dim3(256), 0, st, p);
   }
   if (p.dK || p.dV) {
     SMI_CHECK(p.dK && p.dV, "attention bwd: dK and dV must both be given");
