@@ -35,7 +35,15 @@ CONFIGS = {
     "sd15_512_b4_r4": ("sd1x", 512, 4, 4, "bf16", "ddim", 0.0, 2e-4, 1e-2),        # configs[1]
     "sd14_512_b1_r4": ("sd1x", 512, 1, 4, "fp16", "ddim", 0.0, 2e-4, 1e-2),        # configs[0] shape on the GPU
     "tiny_sdxl": ("tiny_sdxl", 128, 2, 4, "fp16", "euler_a", 0.2, 1e-4, 1e-6),
+    # the shipped SD-1.x default network type (T/data/config.yaml:7): conv + time_emb_proj + attention adaptors
+    "sd14_512_b1_r4_c3lier": ("sd1x", 512, 1, 4, "fp16", "ddim", 0.0, 2e-4, 1e-2),
+    # BASELINE configs[4] per-GPU unit: SD-XL image slider (train_lora-scale-xl.py), one before/after pair per step at
+    # 1024^2, scales +1 / -1: VAE-encode both images, noise them, two adapted UNet passes (+s / -s) with their two backward
+    # passes accumulating one LoRA gradient, AdamW.  Measured by the same JSON contract; `config.step` says what a step is.
+    "image_sdxl_1024_b1_r4": ("sdxl", 1024, 1, 4, "fp16", "ddim", 0.0, 1e-4, 1e-2),
+    "tiny_image_sdxl": ("tiny_sdxl", 128, 1, 4, "fp16", "ddim", 0.0, 1e-4, 1e-2),
 }
+IMAGE_WORKLOADS = ("image_sdxl_1024_b1_r4", "tiny_image_sdxl")
 def pmc_traffic(config):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py); None
     when no such pass exists for this configuration."""
@@ -111,7 +119,22 @@ def host_cpu_info():
     return name, len(cores) or (os.cpu_count() or 1), usable
 
 
-def cpu_baseline(model, lrank, step_flops, gpu_res, seconds_budget=45.0):
+def cgroup_cpu_quota():
+    """CPUs granted by the cgroup quota (v2 cpu.max, v1 cfs quota / period), or None when unlimited / unreadable."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // p)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(model, lrank, step_flops, gpu_res, gpu_batch=2, seconds_budget=45.0):
     """The CPU oracle (kind "port": oracle/slider_ref.py + oracle/unet_ref.py, fp32 PyTorch on the host cores) timed on
     ONE WHOLE STEP in the reference's order: 3 frozen forwards + 1 adapted forward + guidance
     loss + backward + clip + AdamW at UNet batch 2B, B = 1, at a reduced resolution (SD-XL: 512^2 px; 256^2 if a short
@@ -121,8 +144,9 @@ def cpu_baseline(model, lrank, step_flops, gpu_res, seconds_budget=45.0):
     from oracle import slider_ref as R
     from oracle import unet_ref as OU
     cpu_name, phys, usable = host_cpu_info()
-    # the GPU box grants a 16-core share per GPU whatever os.cpu_count() says; oversubscribing it is far slower
-    nthreads = max(1, min(16, usable))
+    # threads = the CPUs this process may actually run on (affinity mask, then the cgroup CPU quota when one is set: a GPU
+    # box grants a share per GPU whatever os.cpu_count() says, and oversubscribing it is far slower), capped at 16
+    nthreads = max(1, min(16, usable, cgroup_cpu_quota() or usable))
     torch.set_num_threads(nthreads)
     ocfg = {"sdxl": OU.sdxl_config, "sd1x": OU.sd1x_config, "tiny_sdxl": OU.tiny_sdxl_config}[model]()
     xl = ocfg.addition_embed_type == "text_time"
@@ -215,6 +239,19 @@ def cpu_baseline(model, lrank, step_flops, gpu_res, seconds_budget=45.0):
     # benchmarked step's ratio backward/forward is taken from its own profile: step = 4F + Bk)
     sample_step_flops = fwd_flops * (4.0 + BWD_OVER_FWD.get(model, 1.12))
     steps_per_s_sample = 1.0 / dt
+    same_size = (lat * 8 == gpu_res) and gpu_batch == 1
+    if same_size:  # the identical workload on both sides (SD-1.x 512^2 B = 1): nothing is extrapolated
+        return {
+            "value": steps_per_s_sample, "unit": "steps/s", "cores": nthreads, "kind": "port",
+            "host": {"cpu": cpu_name, "physical_cores": phys, "usable_logical_cpus": usable, "threads_used": nthreads},
+            "measured": {"steps_per_s": steps_per_s_sample, "seconds_per_step": dt, "forward_s": t_fwd,
+                         "backward_s": t_bwd, "resolution": lat * 8, "batch": 1, "unet_batch": 2,
+                         "tflop_per_step": sample_step_flops / 1e12, "tflops": sample_step_flops / dt / 1e12},
+            "sample": f"ONE whole oracle step (oracle/slider_ref.slider_step: 3 frozen + 1 adapted UNet forward, loss, "
+                      f"backward, clip, AdamW; fp32, {model}, rank {lrank}) at the SAME size as the GPU line "
+                      f"({gpu_res}x{gpu_res} px, B = 1, UNet batch 2): {dt:.1f} s on {nthreads} threads of '{cpu_name}' "
+                      f"({phys} physical cores on the box, {usable} usable); `value` is measured, not extrapolated",
+        }
     return {
         "value": steps_per_s_sample * sample_step_flops / step_flops, "unit": "steps/s", "cores": nthreads,
         "kind": "port",
@@ -234,6 +271,122 @@ def cpu_baseline(model, lrank, step_flops, gpu_res, seconds_budget=45.0):
 # backward / forward algorithmic FLOPs (dX only, attention counted twice): SD-XL 7.545 / 6.761, SD-1.x 0.929 / 0.803
 # (SURVEY.md section 8d); the sample's FLOPs are counted as forward x (4 + this), the same rule bench's profile uses
 BWD_OVER_FWD = {"sdxl": 7.545 / 6.761, "sd1x": 0.929 / 0.803}
+
+
+def image_workload(args, world, rank, rank_devices, unet, net, sched, cfg, model, res, B, lrank, dt_name, lr, wd):
+    """BASELINE configs[4]: the SD-XL image-slider step (trainscripts/imagesliders/train_lora-scale-xl.py:212-381) --
+    per step and GPU: VAE-encode the before/after image pair (latent_dist.sample x scaling_factor), add_noise with one
+    seed, then slider +s on the `high` image and -s on the `low` one (two adapted UNet forwards at UNet batch 2B, two
+    backward passes accumulating one LoRA gradient), all-reduce, AdamW.  Inputs (two [B, 3, res, res] images in [-1, 1],
+    prompt embeddings) are resident in HBM before the timed region; ranks take different pairs."""
+    import sliders_conceptmod_amd.model_util as MU
+    import sliders_conceptmod_amd.vae as PV
+    from sliders_conceptmod_amd.step import ImageSliderStep
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[dt_name]
+    xl = cfg.addition_embed_type == "text_time"
+    vcfg = PV.sdxl_vae_config() if model == "sdxl" else PV.VAEConfig(block_out_channels=(64, 128, 128, 128),
+                                                                      norm_num_groups=16)
+    with torch.device("cuda"):
+        vae = PV.AutoencoderKL(vcfg).to(dtype)
+    init_synthetic_on_device(vae, seed=5)
+    vae.requires_grad_(False).eval()
+    g = torch.Generator().manual_seed(40 + rank)
+    emb = {k: torch.randn(1, 77, cfg.cross_attention_dim, generator=g) for k in ("positive", "neutral", "unconditional")}
+    pdim = cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim
+    pooled = {k: torch.randn(1, pdim, generator=g) for k in emb}
+    time_ids = torch.tensor([[float(res), float(res), 0.0, 0.0, float(res), float(res)]])
+    step = ImageSliderStep(unet, net, sched, lr=lr, weight_decay=wd)
+    cpos, cneu = (step.make_conditioning(emb[k], B, pooled[k], time_ids, uncond=emb["unconditional"],
+                                         uncond_pooled=pooled["unconditional"]) for k in ("positive", "neutral"))
+    img = {k: (torch.rand(B, 3, res, res, generator=torch.Generator().manual_seed(50 + 2 * rank + i)) * 2 - 1).cuda()
+           for i, k in enumerate(("low", "high"))}
+    timestep = sched.timesteps[500]
+    sf = vae.config.scaling_factor
+    noise = torch.randn(B, 4, res // 8, res // 8, generator=torch.Generator().manual_seed(60 + rank)).cuda()
+    t_vae = [0.0]
+
+    def one_step(timed_vae=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed_vae else None
+        if ev:
+            ev[0].record()
+        lat = {k: sf * vae.encode(img[k]).latent_dist.sample(None) for k in img}   # I/train_util.py:213-222
+        noised = {k: sched.add_noise(lat[k], noise, timestep.reshape(1)) for k in img}  # same seed -> same noise (:224-247)
+        if ev:
+            ev[1].record()
+        out = step.train_step(noised["low"], noised["high"], noise, noise, timestep, cpos, cneu, 1.0)
+        if ev:
+            torch.cuda.synchronize()
+            t_vae[0] = ev[0].elapsed_time(ev[1])
+        return out
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(args.warmup, 1)):
+        one_step()
+        if i == 0:
+            torch.cuda.synchronize()
+            if rank == 0:
+                log("first step done (engines created, weights packed, GEMM tiles tuned)")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
+    if world > 1:
+        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tl = [torch.zeros_like(te) for _ in range(world)]
+        torch.distributed.all_gather(tl, te)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in tl]
+        elapsed = max(float(x.item()) for x in tl)
+    engine = unet._engine
+    engine.profile_enable(True)
+    one_step(timed_vae=True)
+    prof = engine.profile_read()
+    engine.profile_enable(False)
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        step_flops = algorithmic_step_flops(prof)
+        mm_ms = prof["gemm"]["ms"] + prof["conv"]["ms"]
+        mm_fl = prof["gemm"]["flops"] + prof["conv"]["flops"]
+        mm_la = prof["gemm"]["launches"] + prof["conv"]["launches"]
+        achieved = mm_fl / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0
+        out = {
+            "metric": "slider train-steps/sec (image slider: 2 adapted UNet fwd+bwd + 2 VAE encodes)",
+            "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dt_name, "data": "synthetic",
+            "config": {"workload": args.config, "unet": model, "resolution": res, "per_gpu_pairs": B, "unet_batch": 2 * B,
+                       "lora_rank": lrank, "train_method": "noxattn", "lora_params": int(net.flat.numel()),
+                       "scales": "1,-1", "scheduler": "ddim", "parallelism": f"dp{world}",
+                       "step": "VAE-encode 2 images + add_noise, slider +s fwd+bwd on `high`, slider -s fwd+bwd on `low`, "
+                               "all-reduce, AdamW (I/train_lora-scale-xl.py:212-381; the two frozen passes whose results "
+                               "its loss never uses are not run)"},
+            "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            "rccl_world_size": world, "rank_devices": rank_devices,
+            "losses_high_low": [float(v) for v in losses.tolist()],
+            "vae_encode_and_noise_ms": t_vae[0],
+            "step_algorithmic_tflop_unet": step_flops / 1e12,
+            "roofline": {"kernel": "gemm_5ph_kernel + gemm_8ph_kernel + gemm_glds_kernel (UNet Linear GEMMs + implicit-GEMM 3x3 convs)",
+                         "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": int(mm_la), "avg_launch_us": mm_ms * 1e3 / max(mm_la, 1),
+                         "algorithmic_tflop_per_step": mm_fl / 1e12},
+            "kernel_classes": {k: {"ms": round(v["ms"], 3), "launches": int(v["launches"]),
+                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] else None,
+                                   "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] else None}
+                               for k, v in prof.items()},
+            "cpu_baseline": None,
+            "cpu_baseline_note": "the CPU oracle step is timed on the text-slider workloads (sd14_512_b1_r4 at the same size)",
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def log(msg):
@@ -275,6 +428,23 @@ def main():
         else:
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # --gpus N is a contract, not a hint: the RCCL-seen world must be N, one rank per DISTINCT device
+    seen_world = torch.distributed.get_world_size() if world > 1 else 1
+    if seen_world != args.gpus:
+        print(f"bench.py --gpus {args.gpus}: the process group has {seen_world} rank(s); launch with "
+              f"torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    rank_devices = None
+    if world > 1:
+        import socket
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = f"{socket.gethostname()}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', local_rank)}:{local_rank}"
+        rank_devices = [None] * world
+        torch.distributed.all_gather_object(rank_devices, ident)
+        if not rehearsal and len(set(rank_devices)) != world:
+            print(f"bench.py: ranks share a device {rank_devices}: one process per GPU is required", file=sys.stderr)
+            sys.exit(2)
+
     from sliders_conceptmod_amd import build as smi_build
     if rank == 0:
         smi_build.build()
@@ -296,12 +466,18 @@ def main():
     if rank == 0:
         log(f"{args.config}: weights initialised ({sum(p.numel() for p in unet.parameters()) / 1e6:.0f} M params)")
     torch.manual_seed(1)
-    net = L.LoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn").to("cuda")
+    c3lier = args.config.endswith("_c3lier")
+    targets = list(L.DEFAULT_TARGET_REPLACE) + (list(L.UNET_TARGET_REPLACE_MODULE_CONV) if c3lier else [])
+    net = L.LoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn",
+                        target_replace=targets).to("cuda")
     with torch.no_grad():  # non-zero up weights so no kernel can short-circuit
         net.flat_up.copy_(torch.randn(net.flat_up.shape, generator=torch.Generator().manual_seed(2)) * 1e-2)
     sched = MU.create_noise_scheduler(sched_name)
     sched.set_timesteps(1000)
     timestep = sched.timesteps[500]  # t = 499
+
+    if args.config in IMAGE_WORKLOADS:
+        return image_workload(args, world, rank, rank_devices, unet, net, sched, cfg, model, res, B, lrank, dt_name, lr, wd)
 
     g = torch.Generator().manual_seed(4 + rank)
     keys = ["target", "positive", "neutral", "unconditional"] + (["negative"] if xl else [])
@@ -404,7 +580,8 @@ def main():
             "dtype": dt_name, "data": "synthetic",
             "config": {"workload": args.config, "unet": model, "resolution": res, "per_gpu_batch": B,
                        "unet_batch": B if args.skip_dead_cfg_half else 2 * B, "global_batch": B * world,
-                       "lora_rank": lrank, "train_method": "noxattn", "lora_params": int(net.flat.numel()),
+                       "lora_rank": lrank, "train_method": "noxattn", "network_type": "c3lier" if c3lier else "lierla",
+                       "lora_params": int(net.flat.numel()),
                        "scheduler": sched_name, "parallelism": f"dp{world}", "pre_roll": "excluded",
                        "skip_dead_cfg_half": bool(args.skip_dead_cfg_half),
                        "dedup_uncond": bool(args.dedup_uncond),
@@ -412,9 +589,12 @@ def main():
                        "1 batched UNet call (3 frozen + 1 adapted sub-batches)"},
             "samples_per_s": args.steps * B * world / elapsed,
             "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            "rccl_world_size": seen_world, "rank_devices": rank_devices,
             "allreduce": None if allreduce_us is None else {
                 "us": allreduce_us, "bytes": int(step.grad.numel() * 4),
-                "what": "flat fp32 LoRA gradient, all-reduce(sum) + divide, on the compute stream (RCCL)"},
+                "what": "flat fp32 LoRA gradient, all-reduce(sum) + divide, on the compute stream (RCCL), issued after "
+                        "the deferred grouped weight-gradient launches of the backward: nothing overlaps it (it is "
+                        "~0.1 % of a step)"},
             "loss": loss_val,
             "preroll": {"forwards": n_pre, "ms": preroll_ms, "unet_batch": 2 * B,
                         "note": "no-grad diffusion(_xl) pre-roll at its mean length, adaptor on; NOT part of `value`",
@@ -441,7 +621,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log("GPU part done; timing the CPU oracle sample: " + json.dumps({k: out[k] for k in ("value", "ms_per_step")}))
             try:
-                out["cpu_baseline"] = cpu_baseline(model, lrank, step_flops, res)
+                out["cpu_baseline"] = cpu_baseline(model, lrank, step_flops, res, B)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

@@ -402,6 +402,9 @@ class ClipEngine:
 
     def encode(self, ids: torch.Tensor, eos_pos: torch.Tensor):
         n, L = ids.shape
+        if L != self.cfg_c.max_positions:  # the engine always runs max_positions tokens per prompt (smi_clip_encode)
+            raise SmiError(f"CLIP text encoder: token ids must be padded to {self.cfg_c.max_positions} positions "
+                           f"(padding='max_length'), got {L}")
         dev = self.workspace.device
         d = self.cfg_c.hidden_size
         last = torch.empty((n, L, d), dtype=self.dtype, device=dev)

@@ -28,6 +28,8 @@
 //
 // Requires M % 256 == 0, N % 320 == 0, K % 64 == 0, K >= 128 (everything else stays on gemm2 / gemm3).  Results are
 // bit-identical to the other generations: same K order per output element, same epilogue arithmetic.
+#include <mutex>
+
 #include "kernels.h"
 
 #include <type_traits>
@@ -580,14 +582,33 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
 
 template <typename T, int MODE>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_5ph_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM4));
-    attr_done = true;
+  // per device (one bit per ordinal, set once under a mutex): the attribute belongs to the function ON the current
+  // device, and engines on two devices / two host threads may share this process; the persistent grid is the device's
+  // CU count, read from the device instead of assumed
+  static std::mutex mu;
+  static uint64_t attr_done = 0;
+  static int cus[64] = {0};
+  int dev = 0;
+  SMI_HIP(hipGetDevice(&dev));
+  int ncu = 256;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64 || !((attr_done >> dev) & 1)) {
+      SMI_HIP(hipFuncSetAttribute((const void*)gemm_5ph_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SMEM4));
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      if (dev >= 0 && dev < 64) {
+        cus[dev] = n;
+        attr_done |= 1ull << dev;
+      }
+      ncu = n;
+    } else {
+      ncu = cus[dev];
+    }
   }
   const int ntiles = (p.M / BM) * (p.N / BN);
-  const int grid = ntiles < 256 ? ntiles : 256;
+  const int grid = ntiles < ncu ? ntiles : ncu;
   hipLaunchKernelGGL((gemm_5ph_kernel<T, MODE>), dim3(grid), dim3(512), SMEM4, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;

@@ -247,3 +247,84 @@ class SliderStep:
                                                self.weight_decay, self.step_count, self.max_grad_norm,
                                                _native.ptr(self.scratch), _native.stream_ptr()), "smi_clip_adamw")
         return self.loss
+
+
+class ImageSliderStep:
+    """The image-slider step (trainscripts/imagesliders/train_lora-scale-xl.py:317-381; SD-1.x twin train_lora-scale.py:
+    283-345) as one device-side sequence, without an autograd graph:
+
+        slider +s : eps = predict_noise(_xl)(high_noised, positive prompt) -> MSE(eps, high_noise) -> backward
+        slider -s : eps = predict_noise(_xl)(low_noised,  neutral prompt)  -> MSE(eps, low_noise)  -> backward
+        (gradients accumulate in the flat fp32 buffer) -> all-reduce -> AdamW
+
+    Same arithmetic and order as `train_lora_scale_xl.image_slider_step` + torch.optim.AdamW (tested against it); the
+    two sides cannot share one UNet pass because their adaptor multipliers differ (+s / -s)."""
+
+    def __init__(self, unet, network, scheduler, *, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, max_grad_norm: float = 0.0, process_group=None):
+        self.unet, self.network, self.scheduler = unet, network, scheduler
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.pg = process_group
+        flat = network.flat
+        self.grad = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.scratch = torch.empty(4096, dtype=torch.float32, device=flat.device)
+        self.losses = torch.zeros(2, dtype=torch.float32, device=flat.device)  # (high side, low side)
+        self.step_count = 0
+        self._lib = _native.lib()
+
+    def make_conditioning(self, text_embeds: torch.Tensor, batch_size: int, pooled: Optional[torch.Tensor] = None,
+                          time_ids: Optional[torch.Tensor] = None, uncond: Optional[torch.Tensor] = None,
+                          uncond_pooled: Optional[torch.Tensor] = None) -> dict:
+        """CFG-doubled conditioning of one side: the prompt paired with the unconditional one (`uncond`,
+        `uncond_pooled`), as the reference does (I/train_lora-scale-xl.py:321-337, I/train_lora-scale.py:283-318); without
+        them the prompt is paired with itself (the same prediction at guidance 1)."""
+        dt, dev = self.unet.dtype, self.unet.device
+        first = text_embeds if uncond is None else uncond
+        c = {"ctx": torch.cat([first, text_embeds]).repeat_interleave(batch_size, dim=0).to(dev, dt).contiguous()}
+        if pooled is not None:
+            first_p = pooled if uncond_pooled is None else uncond_pooled
+            c["text_embeds"] = torch.cat([first_p, pooled]).repeat_interleave(batch_size, dim=0).to(dev, dt).contiguous()
+            c["time_ids"] = torch.cat([time_ids, time_ids]).repeat_interleave(batch_size, dim=0).to(
+                dev, torch.float32).contiguous()
+        return c
+
+    def _side(self, idx, sign_scale, noised, noise, timestep, c, guidance_scale):
+        net = self.network
+        x = self.scheduler.scale_model_input(torch.cat([noised.float()] * 2), timestep).contiguous()
+        n, _, h, w = x.shape
+        engine = self.unet._ensure_engine(n, h, w, c["ctx"].shape[1])
+        net.set_lora_slider(scale=sign_scale)
+        net.__enter__()
+        flat, n_down, mult = net.engine_params()
+        net.__exit__(None, None, None)
+        eps = engine.forward(x, float(timestep), c["ctx"], c.get("text_embeds"), c.get("time_ids"), flat[:n_down],
+                             flat[n_down:], mult, True)
+        pred = torch.empty((n // 2,) + tuple(eps.shape[1:]), dtype=torch.float32, device=eps.device)
+        _native.check(self._lib.smi_cfg_combine(_native.ptr(eps), _native.ptr(pred), pred.numel(),
+                                                float(guidance_scale), _native.stream_ptr()), "smi_cfg_combine")
+        diff = pred - noise.float()                       # MSE in fp32 (I/train_lora-scale-xl.py:338)
+        self.losses[idx] = (diff * diff).mean()
+        dpred = diff * (2.0 / diff.numel())
+        d_eps = torch.cat([dpred * (1.0 - guidance_scale), dpred * guidance_scale])  # d(u + g (t - u))
+        engine.backward(d_eps.contiguous(), self.grad[:n_down], self.grad[n_down:])  # accumulates
+
+    def train_step(self, noised_low, noised_high, noise_low, noise_high, timestep, cond_pos: dict, cond_neu: dict,
+                   scale: float, guidance_scale: float = 1.0, lr: Optional[float] = None) -> torch.Tensor:
+        """One optimisation step; returns the two side losses (high, low) as a device tensor (no host sync)."""
+        net = self.network
+        self.grad.zero_()
+        self._side(0, +scale, noised_high, noise_high, timestep, cond_pos, guidance_scale)
+        self._side(1, -scale, noised_low, noise_low, timestep, cond_neu, guidance_scale)
+        net.set_lora_slider(scale=1)
+        parallel.allreduce_mean_(self.grad, self.pg)
+        self.step_count += 1
+        flat = net.flat
+        _native.check(self._lib.smi_clip_adamw(_native.ptr(flat), _native.ptr(self.grad), _native.ptr(self.exp_avg),
+                                               _native.ptr(self.exp_avg_sq), flat.numel(),
+                                               self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
+                                               self.weight_decay, self.step_count, self.max_grad_norm,
+                                               _native.ptr(self.scratch), _native.stream_ptr()), "smi_clip_adamw")
+        return self.losses

@@ -29,7 +29,8 @@ def encode(text_encoder, tokenizer, prompt, device, dtype):
     return text_encoder[0](tokens.to(text_encoder[0].device))[0].to(device, dtype)
 
 
-def train(config: RootConfig, prompts: list, device, models=None, on_step_complete=None, save_file=True):
+def train(config: RootConfig, prompts: list, device, models=None, on_step_complete=None, save_file=True,
+          fused_step: bool = False):
     metadata = {"prompts": ",".join([p.model_dump_json() for p in prompts]), "config": config.model_dump_json()}
     save_path = Path(config.save.path)
     # train_lora.py:44-46: `modules = DEFAULT_TARGET_REPLACE; modules += UNET_TARGET_REPLACE_MODULE_CONV` mutates the list
@@ -83,9 +84,58 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
                                                  settings=settings))
     del tokenizer, text_encoder
 
+    # --fused_step: the pre-roll and the 4-pass step run through SliderStep (one batched UNet pass, native loss / AdamW,
+    # no autograd graph) -- the path bench.py measures.  Same arithmetic and RNG draw order as the loop below (tested).
+    stepper = None
+    if fused_step:
+        from .step import SliderStep
+        name = config.train.optimizer.lower()
+        wd = optimizer_kwargs.get("weight_decay", 1e-2 if name == "adamw" else 0.0)
+        if name not in ("adam", "adamw") or (name == "adam" and wd != 0.0) or optimizer_kwargs.get("amsgrad"):
+            raise ValueError("--fused_step implements Adam / AdamW (decoupled weight decay) only")
+        stepper = SliderStep(unet, network, noise_scheduler, lr=config.train.lr, weight_decay=wd,
+                             eps=optimizer_kwargs.get("eps", 1e-8), betas=optimizer_kwargs.get("betas", (0.9, 0.999)),
+                             max_grad_norm=0.0, cfg_scale=1.0)
+    cond_cache = {}
+
     pbar = tqdm(range(config.train.iterations), disable=rank != 0)
     loss = None
     for i in pbar:
+        if stepper is not None:
+            with torch.no_grad():
+                noise_scheduler.set_timesteps(config.train.max_denoising_steps, device=device)
+                prompt_pair = prompt_pairs[torch.randint(0, len(prompt_pairs), (1,)).item()]
+                timesteps_to = torch.randint(1, config.train.max_denoising_steps, (1,)).item()
+                height, width = prompt_pair.resolution, prompt_pair.resolution
+                if prompt_pair.dynamic_resolution:
+                    height, width = train_util.get_random_resolution_in_bucket(prompt_pair.resolution)
+                bs = prompt_pair.batch_size
+                latents = train_util.get_initial_latents(noise_scheduler, bs, height, width, 1)
+                if world > 1:
+                    latents = latents[parallel.shard_slice(bs, rank, world)]
+                    bs = bs // world
+                latents = latents.to(device, dtype=torch.float32)
+                c = cond_cache.get((id(prompt_pair), bs))
+                if c is None:
+                    emb = {k: getattr(prompt_pair, k) for k in ("target", "positive", "neutral", "unconditional")}
+                    c = cond_cache[(id(prompt_pair), bs)] = stepper.make_conditioning(emb, bs)
+                denoised_latents = stepper.preroll(latents, c, timesteps_to, 3)
+                noise_scheduler.set_timesteps(1000)
+                current_timestep = noise_scheduler.timesteps[
+                    int(timesteps_to * 1000 / config.train.max_denoising_steps)]
+                loss = stepper.train_step(denoised_latents, current_timestep, c, prompt_pair.action,
+                                          prompt_pair.guidance_scale, lr=lr_scheduler.get_last_lr()[0])
+            lv = float(loss.item())  # the one host sync per step, as the reference's loss.item() (train_lora.py:292)
+            pbar.set_description(f"Loss*1k: {lv * 1000:.4f}")
+            optimizer.step()  # no gradients: a no-op that keeps torch's "optimizer before scheduler" order
+            lr_scheduler.step()
+            if on_step_complete is not None:
+                on_step_complete(i, lv)
+            if save_file and rank == 0 and i % config.save.per_steps == 0 and i != 0 and \
+                    i != config.train.iterations - 1:
+                save_path.mkdir(parents=True, exist_ok=True)
+                network.save_weights(save_path / f"{config.save.name}_{i}steps.pt", dtype=save_weight_dtype)
+            continue
         with torch.no_grad():
             noise_scheduler.set_timesteps(config.train.max_denoising_steps, device=device)
             optimizer.zero_grad()
@@ -164,7 +214,7 @@ def main(args):
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     else:
         device = torch.device(f"cuda:{args.device}")
-    train(config, prompts, device)
+    train(config, prompts, device, fused_step=args.fused_step)
 
 
 def build_parser():
@@ -176,6 +226,9 @@ def build_parser():
     parser.add_argument("--name", type=str, required=False, default=None, help="Name of the slider.")
     parser.add_argument("--attributes", type=str, required=False, default=None,
                         help="attritbutes to disentangle (comma seperated string)")
+    parser.add_argument("--fused_step", action="store_true",
+                        help="run the pre-roll and the 4-pass step through SliderStep (one batched UNet pass, native "
+                             "loss / AdamW, no autograd graph) -- the path bench.py measures")
     return parser
 
 

@@ -5,26 +5,14 @@ one (:283-318), image pairs resized to 256 x 256 (:219), `.pt` output.  Same CLI
 
     python -m sliders_conceptmod_amd.train_lora_scale --name eyesize --rank 4 --alpha 1 --config_file data/config.yaml \
            --folder_main datasets/eyesize --folders "bigsize, smallsize" --scales "1, -1" """
-import torch
-
-from . import config_util, prompt_util
-from .train_lora_scale_xl import build_parser, train
+from . import train_lora_scale_xl
+from .train_lora_scale_xl import build_parser, train  # noqa: F401  (re-exported: the reference script's names)
 
 
-def main(args):
-    config = config_util.load_config_from_yaml(args.config_file)
-    if args.name is not None:
-        config.save.name = args.name
-    attributes = [a.strip() for a in args.attributes.split(",")] if args.attributes is not None else []
-    config.network.alpha = args.alpha
-    config.network.rank = args.rank
-    config.save.name += f"_alpha{args.alpha}_rank{config.network.rank}_{config.network.training_method}"
-    config.save.path += f"/{config.save.name}"
-    prompts = prompt_util.load_prompts_from_yaml(config.prompts_file, attributes)
-    device = torch.device(f"cuda:{args.device}")
-    folders = [f.strip() for f in args.folders.split(",")]
-    scales = [float(s.strip()) for s in args.scales.split(",")]
-    train(config, prompts, device, args.folder_main, folders, scales, rank=args.rank, xl=False)
+def main(args, models=None, vae=None):
+    """Same flags, launch rules (torch.distributed.run -> one rank per GPU over RCCL) and code path as the SD-XL trainer,
+    with the SD-1.x conditioning / 256 x 256 pairs / [1, max - 1) timestep draw selected by xl=False."""
+    return train_lora_scale_xl.main(args, xl=False, models=models, vae=vae)
 
 
 if __name__ == "__main__":

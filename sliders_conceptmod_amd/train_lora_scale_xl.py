@@ -28,15 +28,17 @@ from .train_lora_xl import encode_xl
 def image_slider_step(unet, network, scheduler, lat_low, lat_high, noise_low, noise_high, timestep, pos, neu,
                       add_time_ids, scale: float, guidance_scale: float = 1.0, uncond=None):
     """The two adapted passes + two backward()s of one image-slider step; returns (loss_high, loss_low).
-    SD-XL (`pos` / `neu` are PromptEmbedsXL): each prompt is paired with itself in the CFG batch
-    (I/train_lora-scale-xl.py:321-329).  SD-1.x (`pos` / `neu` / `uncond` are [1, 77, D] tensors): paired with the
-    unconditional prompt (I/train_lora-scale.py:283-318)."""
+    The reference pairs every prompt with the UNCONDITIONAL one in the CFG batch at guidance_scale = 1
+    (I/train_lora-scale-xl.py:321-337, I/train_lora-scale.py:283-318): pass `uncond` (a PromptEmbedsXL for SD-XL, a
+    [1, 77, D] tensor for SD-1.x) for exactly that.  With `uncond=None` an SD-XL prompt is paired with itself, which at
+    guidance 1 is the same prediction (u + 1 (t - u) == t) -- kept for callers that hold no unconditional embedding."""
     bs = lat_high.shape[0]
     xl = hasattr(pos, "pooled_embeds")
 
     def cond(e):
-        return dict(text_embeddings=train_util.concat_embeddings(e.text_embeds, e.text_embeds, bs),
-                    add_text_embeddings=train_util.concat_embeddings(e.pooled_embeds, e.pooled_embeds, bs),
+        u = e if uncond is None else uncond
+        return dict(text_embeddings=train_util.concat_embeddings(u.text_embeds, e.text_embeds, bs),
+                    add_text_embeddings=train_util.concat_embeddings(u.pooled_embeds, e.pooled_embeds, bs),
                     add_time_ids=train_util.concat_embeddings(add_time_ids, add_time_ids, bs))
 
     losses = []
@@ -68,11 +70,12 @@ _IMAGE_EXT = (".png", ".jpg", ".jpeg", ".webp")  # I/train_lora-scale-xl.py:217
 
 
 def train(config, prompts, device, folder_main, folders, scales, models=None, rank=4, vae=None, image_size=None,
-          xl=True):
+          xl=True, fused_step: bool = False, on_step_complete=None):
     """`vae` (an AutoencoderKL, default: loaded next to the UNet) is only needed when the folders hold image files;
     `image_size` is what the pairs are resized to (the reference hard-codes (512, 512) for SD-XL,
     I/train_lora-scale-xl.py:220, and (256, 256) for SD-1.x, I/train_lora-scale.py:219).  `xl=False` is the SD-1.x twin
-    (train_lora_scale.py)."""
+    (train_lora_scale.py).  `fused_step` runs the two-sided step through step.ImageSliderStep (no autograd graph, native
+    AdamW) -- same arithmetic, tested against the autograd loop."""
     weight_dtype = config_util.parse_precision(config.train.precision)
     tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
         config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=xl)
@@ -96,17 +99,21 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
                                                                  lr=config.train.lr)
     lr_scheduler = train_util.get_lr_scheduler(config.train.lr_scheduler, optimizer,
                                                max_iterations=config.train.iterations, lr_min=config.train.lr / 100)
-    settings = prompts[0]
-    unc = None
+    # every prompt entry is encoded (target / positive / neutral / unconditional, I/train_lora-scale-xl.py:136-166) and one
+    # is drawn per step from the torch RNG BEFORE timesteps_to (:183-191): multi-entry prompt files and the draw order
+    # are the reference's
+    cache, pairs = {}, []
     with torch.no_grad():
         if xl:
-            pos = encode_xl(text_encoders, tokenizers, settings.positive, device, weight_dtype)
-            neu = encode_xl(text_encoders, tokenizers, settings.neutral, device, weight_dtype)
+            enc = lambda p_: encode_xl(text_encoders, tokenizers, p_, device, weight_dtype)  # noqa: E731
         else:
             from .train_lora import encode
-            pos = encode(text_encoders, tokenizers, settings.positive, device, weight_dtype)
-            neu = encode(text_encoders, tokenizers, settings.neutral, device, weight_dtype)
-            unc = encode(text_encoders, tokenizers, settings.unconditional, device, weight_dtype)
+            enc = lambda p_: encode(text_encoders, tokenizers, p_, device, weight_dtype)  # noqa: E731
+        for settings in prompts:
+            for p_ in (settings.target, settings.positive, settings.neutral, settings.unconditional):
+                if p_ not in cache:
+                    cache[p_] = enc(p_)
+            pairs.append((settings, cache[settings.positive], cache[settings.neutral], cache[settings.unconditional]))
     # folder <-> scale pairing by ORIGINAL index, as the reference does (folders[scales == s][0],
     # I/train_lora-scale-xl.py:213-214); a length mismatch raises as there (:452-453)
     if len(scales) != len(folders):
@@ -130,11 +137,24 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     size = image_size or ((512, 512) if xl else (256, 256))
     save_path = Path(config.save.path)
     save_dtype = config_util.parse_precision(config.train.precision)
+    stepper = None
+    if fused_step:
+        from .step import ImageSliderStep
+        if config.train.optimizer.lower() not in ("adam", "adamw"):
+            raise ValueError("--fused_step implements Adam / AdamW only")
+        stepper = ImageSliderStep(unet, network, noise_scheduler, lr=config.train.lr,
+                                  weight_decay=1e-2 if config.train.optimizer.lower() == "adamw" else 0.0)
+    cond_cache = {}
+    network.training_losses = []
     for i in tqdm(range(config.train.iterations), disable=rank_ != 0):
         noise_scheduler.set_timesteps(config.train.max_denoising_steps, device=device)
         optimizer.zero_grad()
+        settings, pos, neu, unc = pairs[torch.randint(0, len(pairs), (1,)).item()]
         # I/train_lora-scale-xl.py:191-193 draws from [1, max); the SD-1.x script from [1, max - 1) (I/train_lora-scale.py:186)
         timesteps_to = torch.randint(1, config.train.max_denoising_steps - (0 if xl else 1), (1,)).item()
+        height, width = settings.resolution, settings.resolution
+        if settings.dynamic_resolution:
+            height, width = train_util.get_random_resolution_in_bucket(settings.resolution)
         scale_to_look = abs(random.choice(scales))
         f_low, f_high = folder_of[-scale_to_look], folder_of[scale_to_look]
         name = names[(random.randint(0, len(names) - 1) + rank_) % len(names)]  # ranks take different pairs
@@ -147,7 +167,6 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
                 pair.append(train_util.get_noisy_image(img, vae, torch.manual_seed(seed), unet, noise_scheduler,
                                                        start_timesteps=0, total_timesteps=timesteps_to))
             (nl, noise_low), (nh, noise_high) = pair
-            h, w = size[1], size[0]
         else:
             lat_low = _load_latent(os.path.join(folder_main, f_low, name)).unsqueeze(0).float()
             lat_high = _load_latent(os.path.join(folder_main, f_high, name)).unsqueeze(0).float()
@@ -158,15 +177,37 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
             noise_high = torch.randn(lat_high.shape, generator=g)
             nl = noise_scheduler.add_noise(lat_low, noise_low, t).to(device)
             nh = noise_scheduler.add_noise(lat_high, noise_high, t).to(device)
-            h, w = lat_low.shape[-2] * 8, lat_low.shape[-1] * 8
-        tid = train_util.get_add_time_ids(h, w, dtype=torch.float32).to(device) if xl else None
+        if settings.batch_size != nh.shape[0]:  # the reference repeats the embeddings batch_size times over ONE image pair
+            raise ValueError(f"prompt batch_size {settings.batch_size} != {nh.shape[0]} image pair(s) per step")
         noise_scheduler.set_timesteps(1000)
+        # the added time ids follow the PROMPT's resolution (and dynamic_crops), not the image size (:249-254)
+        tid = train_util.get_add_time_ids(height, width, dynamic_crops=settings.dynamic_crops,
+                                          dtype=torch.float32).to(device) if xl else None
         cur_t = noise_scheduler.timesteps[int(timesteps_to * 1000 / config.train.max_denoising_steps)]
-        image_slider_step(unet, network, noise_scheduler, nl, nh, noise_low.to(device), noise_high.to(device), cur_t,
-                          pos, neu, tid, scale_to_look, uncond=unc)
-        parallel.allreduce_mean_(network.flat.grad)
-        optimizer.step()
+        if stepper is not None:
+            ckey = (id(settings), height, width)
+            cc = None if settings.dynamic_crops else cond_cache.get(ckey)
+            if cc is None:
+                if xl:
+                    cc = tuple(stepper.make_conditioning(e.text_embeds, 1, e.pooled_embeds, tid, uncond=unc.text_embeds,
+                                                         uncond_pooled=unc.pooled_embeds) for e in (pos, neu))
+                else:
+                    cc = tuple(stepper.make_conditioning(e, 1, uncond=unc) for e in (pos, neu))
+                cond_cache[ckey] = cc
+            with torch.no_grad():
+                losses = stepper.train_step(nl, nh, noise_low.to(device), noise_high.to(device), cur_t, cc[0], cc[1],
+                                            scale_to_look, lr=lr_scheduler.get_last_lr()[0])
+            lh, ll = (float(v) for v in losses.tolist())
+        else:
+            lh, ll = image_slider_step(unet, network, noise_scheduler, nl, nh, noise_low.to(device),
+                                       noise_high.to(device), cur_t, pos, neu, tid, scale_to_look, uncond=unc)
+            lh, ll = float(lh), float(ll)
+            parallel.allreduce_mean_(network.flat.grad)
+        optimizer.step()  # fused: no gradients, a no-op that keeps torch's "optimizer before scheduler" order
         lr_scheduler.step()
+        network.training_losses.append((lh, ll))
+        if on_step_complete is not None:
+            on_step_complete(i, lh, ll)
         if rank_ == 0 and i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1:
             save_path.mkdir(parents=True, exist_ok=True)  # I/train_lora-scale-xl.py:402-412
             network.save_weights(save_path / f"{config.save.name}_{i}steps.pt", dtype=save_dtype)
@@ -176,7 +217,23 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     return network
 
 
-def main(args):
+def launch_device(args):
+    """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment): RCCL process
+    group, device = LOCAL_RANK -- exactly as train_lora_xl.main does.  `SMI_DIST_BACKEND=gloo` is for rehearsals on a
+    box with fewer GPUs than ranks (tests)."""
+    if str(args.device) == "cpu":
+        raise ValueError("--device cpu: the product path has no CPU fallback (the CPU oracle lives under oracle/)")
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        backend = os.environ.get("SMI_DIST_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else int(args.device)
+        torch.cuda.set_device(local)
+        if not torch.distributed.is_initialized():
+            torch.distributed.init_process_group(backend)
+        return torch.device("cuda", local)
+    return torch.device(f"cuda:{args.device}")
+
+
+def main(args, xl: bool = True, models=None, vae=None):
     config = config_util.load_config_from_yaml(args.config_file)
     if args.name is not None:
         config.save.name = args.name
@@ -186,10 +243,11 @@ def main(args):
     config.save.name += f"_alpha{args.alpha}_rank{config.network.rank}_{config.network.training_method}"
     config.save.path += f"/{config.save.name}"
     prompts = prompt_util.load_prompts_from_yaml(config.prompts_file, attributes)
-    device = torch.device(f"cuda:{args.device}")
+    device = launch_device(args)
     folders = [f.strip() for f in args.folders.split(",")]
     scales = [float(s.strip()) for s in args.scales.split(",")]
-    train(config, prompts, device, args.folder_main, folders, scales, rank=args.rank)
+    return train(config, prompts, device, args.folder_main, folders, scales, rank=args.rank, xl=xl, models=models,
+                 vae=vae, fused_step=getattr(args, "fused_step", False))
 
 
 def build_parser():
@@ -204,6 +262,8 @@ def build_parser():
     p.add_argument("--stylecheck", type=str, default=None)
     p.add_argument("--folders", type=str, default="verylow, low, high, veryhigh")
     p.add_argument("--scales", type=str, default="-2, -1, 1, 2")
+    p.add_argument("--fused_step", action="store_true",
+                   help="run the two-sided step through ImageSliderStep (no autograd graph, native AdamW)")
     return p
 
 

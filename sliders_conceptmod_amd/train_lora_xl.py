@@ -122,10 +122,22 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
                                                                      e.pooled_embeds, bs),
                     add_time_ids=train_util.concat_embeddings(add_time_ids, add_time_ids, bs))
 
-            with network:
-                denoised_latents = train_util.diffusion_xl(unet, noise_scheduler, latents, **cond(prompt_pair.target),
-                                                           start_timesteps=0, total_timesteps=timesteps_to,
-                                                           guidance_scale=guidance_scale)
+            c = None
+            if stepper is not None:  # fused: conditioning tensors per (prompt pair, batch, size), pre-roll without autograd
+                ckey = (id(prompt_pair), bs, height, width)
+                c = None if prompt_pair.dynamic_crops else cond_cache.get(ckey)
+                if c is None:
+                    emb = {k: getattr(prompt_pair, k).text_embeds for k in
+                           ("target", "positive", "neutral", "unconditional", "negative")}
+                    pooled = {k: getattr(prompt_pair, k).pooled_embeds for k in emb}
+                    c = cond_cache[ckey] = stepper.make_conditioning(emb, bs, pooled, add_time_ids)
+                denoised_latents = stepper.preroll(latents, c, timesteps_to, guidance_scale)
+            else:
+                with network:
+                    denoised_latents = train_util.diffusion_xl(unet, noise_scheduler, latents,
+                                                               **cond(prompt_pair.target), start_timesteps=0,
+                                                               total_timesteps=timesteps_to,
+                                                               guidance_scale=guidance_scale)
             noise_scheduler.set_timesteps(1000)
             current_timestep = noise_scheduler.timesteps[int(timesteps_to * 1000 / config.train.max_denoising_steps)]
             if stepper is None:
@@ -139,16 +151,10 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
                                                                denoised_latents, **cond(prompt_pair.negative),
                                                                guidance_scale=guidance_scale)
         if stepper is not None:
-            emb = {k: getattr(prompt_pair, k).text_embeds for k in
-                   ("target", "positive", "neutral", "unconditional", "negative")}
-            pooled = {k: getattr(prompt_pair, k).pooled_embeds for k in emb}
-            ckey = (id(prompt_pair), bs, height, width)
-            c = None if prompt_pair.dynamic_crops else cond_cache.get(ckey)
-            if c is None:
-                c = cond_cache[ckey] = stepper.make_conditioning(emb, bs, pooled, add_time_ids)
             lr_now = lr_scheduler.get_last_lr()[0]
             loss = stepper.train_step(denoised_latents, current_timestep, c, prompt_pair.action,
                                       prompt_pair.guidance_scale, lr=lr_now)
+            optimizer.step()  # no gradients: a no-op that keeps torch's "optimizer before scheduler" order
         else:
             with network:
                 target_latents = train_util.predict_noise_xl(unet, noise_scheduler, current_timestep,

@@ -290,8 +290,8 @@ class UNet2DConditionModel(nn.Module):
         net = self._lora_network
         sites = net.engine_sites() if net is not None else []
         # packed weights depend on dtype / device / adapted sites only; shapes are plans of the same engine
-        key = (self.dtype, str(self.device), tuple((s["target"], s["off_down"], s["off_up"], s["rank"], s["scale"])
-                                                   for s in sites))
+        key = (self.dtype, str(self.device), tuple((s["target"], s["off_down"], s["off_up"], s["rank"], s["scale"],
+                                                    s.get("off_dora", -1)) for s in sites))  # LoRA vs DoRA differ here
         if self._engine is not None and self._engine_key == key:
             e = self._engine
             if (h, w, ctx_len) == (e.h, e.w, e.ctx_len) and n <= e.batch and n_adapted <= e.batch_adapted:

@@ -112,6 +112,9 @@ class _EncoderOutput:
         self.latent_dist = latent_dist
 
 
+_DEPRECATED_ATTN_NAMES = ((".query.", ".to_q."), (".key.", ".to_k."), (".value.", ".to_v."), (".proj_attn.", ".to_out.0."))
+
+
 class AutoencoderKL(nn.Module):
     def __init__(self, cfg: VAEConfig):
         super().__init__()
@@ -130,7 +133,19 @@ class AutoencoderKL(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts a full diffusers AutoencoderKL state dict: the decoder / post_quant_conv entries are not used."""
-        sd = {k: v for k, v in state_dict.items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+        sd = {}
+        for k, v in state_dict.items():
+            if not (k.startswith("encoder.") or k.startswith("quant_conv.")):
+                continue
+            # SD-1.x era checkpoints name the mid-block attention query / key / value / proj_attn (diffusers renames them
+            # when it loads, `_convert_deprecated_attention_blocks`); some store them as 1 x 1 conv kernels [C, C, 1, 1]
+            for old, new in _DEPRECATED_ATTN_NAMES:
+                if old in k:
+                    k = k.replace(old, new)
+                    if v.ndim == 4 and v.shape[-2:] == (1, 1):
+                        v = v.reshape(v.shape[0], v.shape[1])
+                    break
+            sd[k] = v
         return super().load_state_dict(sd, strict=strict)
 
     def _engine(self, n, h, w):

@@ -75,6 +75,10 @@ def test_clip_text_encoder_matches_oracle(which, dtype, bar):
     out2 = m(ids2.cuda(), output_hidden_states=True)
     assert torch.equal(out2.last_hidden_state[:, :5], out.last_hidden_state[:, :5])
     assert not torch.equal(out2.last_hidden_state[:, 5:], out.last_hidden_state[:, 5:])
+    if which == "tiny_quick_gelu":  # the engine always runs max_positions tokens; anything else must raise
+        from sliders_conceptmod_amd import _native
+        with pytest.raises(_native.SmiError, match="padded to"):
+            m(ids[:, :10].cuda())
 
 
 def test_clip_matches_transformers_directly():

@@ -173,15 +173,15 @@ def test_kernel_generations_agree_at_headline_size(tmp_path):
     """Size-independent property at BASELINE's full size (SD-XL 1024^2, B = 2, rank 4: 16 UNet samples per pass, where
     the CPU oracle would need hours): every GEMM generation accumulates over K in the same order and applies the same
     epilogue arithmetic, so a whole train step run with the tile selection forced to the plain 128 x 128 LDS-DMA kernel
-    on one stream must give the SAME loss, LoRA gradient and updated parameters as the default selection (256 x 256
-    8-phase kernel, 128 x 160 tiles, skinny LoRA products, second stream for the weight gradients).  A race or an
-    indexing slip in any of those at the real shapes shows up here."""
+    must give the SAME loss, LoRA gradient and updated parameters as the default selection (the tuned mix of the
+    256 x 320 persistent kernel, the 256 x 256 8-phase kernel, 128 x 160 tiles in their 4- and 8-wave forms and the
+    deep-prefetch loop).  A race or an indexing slip in any of those at the real shapes shows up here."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for name, env in (("default", {}), ("plain", {"SMI_GEMM": "128", "SMI_SIDE_STREAM": "0"})):
+    for name, env in (("default", {}), ("plain", {"SMI_GEMM": "128"})):
         out = tmp_path / f"{name}.pt"
         e = dict(os.environ)
         e.update(env)

@@ -257,6 +257,52 @@ def test_vae_container_matches_oracle_keys_and_fails_loudly_off_gpu():
         pv.half().encode(torch.zeros(1, 3, 64, 64))
 
 
+def test_vae_loads_deprecated_attention_names():
+    """SD-1.x era VAE checkpoints name the mid-block attention query / key / value / proj_attn (some as
+    1 x 1 conv kernels); diffusers renames them on load, so must this container -- strictly, values intact."""
+    import sliders_conceptmod_amd.vae as PV
+    src = PV.init_synthetic_(PV.AutoencoderKL(PV.sd_vae_config()), seed=3)
+    new_sd = {k: v.clone() for k, v in src.state_dict().items()}
+    old_sd = {}
+    ren = ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn."))
+    n_renamed = 0
+    for k, v in new_sd.items():
+        for a, b in ren:
+            if a in k:
+                k = k.replace(a, b)
+                n_renamed += 1
+                if k.endswith("weight"):
+                    v = v.reshape(v.shape[0], v.shape[1], 1, 1)  # the conv-kernel form of the oldest checkpoints
+                break
+        old_sd[k] = v
+    assert n_renamed == 8
+    dst = PV.AutoencoderKL(PV.sd_vae_config())
+    dst.load_state_dict(old_sd)  # strict
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, new_sd[k]), k
+
+
+def test_engine_cache_key_tells_dora_from_lora():
+    """ADVICE r2: a DoRANetwork and a LoRANetwork with the same rank / alpha / targets have identical down / up offsets;
+    the engine key must still differ (the packed engine holds DoRA sites and delta-weight buffers or it does not)."""
+    import dataclasses
+    import sliders_conceptmod_amd.dora as D
+    import sliders_conceptmod_amd.lora as L
+    import sliders_conceptmod_amd.unet as PU
+    from oracle import unet_ref as OU
+    pu = PU.UNet2DConditionModel(PU.UNetConfig(**dataclasses.asdict(OU.tiny_sdxl_config())))
+    keys = []
+    for cls in (L.LoRANetwork, D.DoRANetwork):
+        net = cls(pu, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+        sites = net.engine_sites()
+        keys.append(tuple((s["target"], s["off_down"], s["off_up"], s["rank"], s["scale"], s.get("off_dora", -1))
+                          for s in sites))
+    assert [k[:5] for k in keys[0]] == [k[:5] for k in keys[1]]  # the collision the advisor described ...
+    assert keys[0] != keys[1]                                     # ... which the sixth field resolves
+    import inspect
+    assert "off_dora" in inspect.getsource(PU.UNet2DConditionModel._ensure_engine)
+
+
 def test_vae_image_processor_preprocess():
     import numpy as np
     from PIL import Image

@@ -109,8 +109,6 @@ def test_cli_train_final_lora_tensors_elementwise(goldens, tmp_path, model, fuse
     t, man = goldens
     meta = man[f"traj_smooth/{model}"]
     xl = model.endswith("xl")
-    if fused and not xl:
-        pytest.skip("--fused_step is an SD-XL trainer option")
     eps = meta["optimizer_kwargs"]["eps"]
     cfg, prompts, models = make(model, tmp_path, xl, optimizer_args="" if xl else f"eps={eps}")
     losses = []
@@ -123,7 +121,7 @@ def test_cli_train_final_lora_tensors_elementwise(goldens, tmp_path, model, fuse
     else:
         from sliders_conceptmod_amd.train_lora import train
         net = train(cfg, prompts, torch.device("cuda:0"), models=models,
-                    on_step_complete=lambda i, l: losses.append(l))
+                    on_step_complete=lambda i, l: losses.append(l), fused_step=fused)
     for a, b in zip(losses, meta["losses"]):
         assert abs(a - b) <= 0.015 * abs(b), (losses, meta["losses"])
     # reload what was written (the saved file is the product) and compare every stored tensor
@@ -164,18 +162,85 @@ def test_cli_train_final_lora_tensors_elementwise(goldens, tmp_path, model, fuse
     assert worst_t <= 2.5e-2, worst_t
 
 
-def test_fused_step_matches_autograd_step(goldens, tmp_path):
-    """SliderStep (native loss / clip / AdamW, no autograd) == the drop-in autograd loop, same seeds."""
-    from sliders_conceptmod_amd.train_lora_xl import train
-    res = []
+@pytest.mark.parametrize("model", ["tiny_sd1x", "tiny_sdxl"])
+def test_fused_step_matches_autograd_step(goldens, tmp_path, model):
+    """--fused_step (SliderStep: native pre-roll, one batched UNet pass, native loss / clip / AdamW, no autograd) == the
+    drop-in autograd loop, same seeds -- both text trainers (train_lora.py: DDIM, no clip; train_lora_xl.py: Euler-a,
+    clip 0.2, cosine LR)."""
+    xl = model.endswith("xl")
+    res, losses = [], []
     for fused in (False, True):
-        cfg, prompts, models = make("tiny_sdxl", tmp_path, True)
+        cfg, prompts, models = make(model, tmp_path, xl)
         torch.manual_seed(1)
-        net = train(cfg, prompts, torch.device("cuda:0"), rank=4, save_file=True, models=models, fused_step=fused)
+        ls = []
+        if xl:
+            from sliders_conceptmod_amd.train_lora_xl import train
+            net = train(cfg, prompts, torch.device("cuda:0"), rank=4, save_file=True, models=models, fused_step=fused)
+            ls = net.training_losses
+        else:
+            from sliders_conceptmod_amd.train_lora import train
+            net = train(cfg, prompts, torch.device("cuda:0"), models=models, fused_step=fused,
+                        on_step_complete=lambda i, l: ls.append(l))
         res.append(net.flat.detach().clone())
+        losses.append(list(ls))
     a, b = res
     rel = float((a - b).norm() / b.norm())
+    print(f"{model}: fused vs autograd parameter distance {rel:.2e}; losses {losses}")
     assert rel < 2e-3, f"fused vs autograd parameter distance {rel:.2e}"
+    # the first loss is bit-equal; later ones see Adam's sign-like first updates amplify fp32-order differences (measured
+    # 2e-3 on SD-1.x at lr 2e-3)
+    assert losses[0][0] == pytest.approx(losses[1][0], rel=1e-5)
+    for x, y in zip(*losses):
+        assert abs(x - y) <= 1e-2 * abs(y), losses
+
+
+def _latent_folders(root, n=3, hw=16):
+    g = torch.Generator().manual_seed(5)
+    for folder, bias in (("big", 0.3), ("small", -0.3)):
+        (root / folder).mkdir(parents=True)
+        for i in range(n):
+            torch.save(torch.randn(4, hw, hw, generator=g) + bias, root / folder / f"p{i}.pt")
+
+
+def _image_cfg(tmp_path, xl, iterations=4, eps=None):
+    import sliders_conceptmod_amd.config_util as CU
+    import sliders_conceptmod_amd.prompt_util as PRU
+    cfg = CU.RootConfig(
+        prompts_file="unused",
+        pretrained_model=CU.PretrainedModelConfig(name_or_path="synthetic://tiny_sdxl" if xl else "synthetic://tiny_sd1x"),
+        network=CU.NetworkConfig(type="lierla", rank=4, alpha=1.0, training_method="noxattn"),
+        train=CU.TrainConfig(precision="float16", noise_scheduler="ddim", iterations=iterations, lr=1e-3,
+                             optimizer="AdamW", lr_scheduler="constant", max_denoising_steps=10),
+        save=CU.SaveConfig(name="img", path=str(tmp_path / "out"), per_steps=1000), logging=CU.LoggingConfig(),
+        other=CU.OtherConfig())
+    prompts = [PRU.PromptSettings(target="t", positive="big", neutral="small", unconditional="", resolution=128),
+               PRU.PromptSettings(target="t", positive="large", neutral="tiny", unconditional="", resolution=128)]
+    return cfg, prompts
+
+
+@pytest.mark.parametrize("xl", [True, False])
+def test_image_slider_fused_step_matches_autograd_loop(tmp_path, xl):
+    """train_lora_scale(_xl).train(fused_step=True) -- step.ImageSliderStep: two adapted forward + backward pairs at
+    slider +s / -s accumulating into one flat gradient, native AdamW, no autograd graph -- against the autograd loop
+    (image_slider_step + torch.optim.AdamW) on the same folders, seeds and prompt file (two entries: the per-step
+    prompt-pair draw of I/train_lora-scale-xl.py:183 is exercised)."""
+    import random
+    from sliders_conceptmod_amd.train_lora_scale_xl import train
+    _latent_folders(tmp_path / "data")
+    res, losses = [], []
+    for fused in (False, True):
+        cfg, prompts = _image_cfg(tmp_path, xl)
+        torch.manual_seed(0)
+        random.seed(0)
+        net = train(cfg, prompts, torch.device("cuda:0"), str(tmp_path / "data"), ["big", "small"], [1, -1], xl=xl,
+                    fused_step=fused)
+        res.append(net.flat.detach().clone())
+        losses.append(net.training_losses)
+    rel = float((res[1] - res[0]).norm() / res[0].norm())
+    print(f"xl={xl}: fused vs autograd parameter distance {rel:.2e}")
+    assert rel < 2e-3, rel
+    for (ah, al), (bh, bl) in zip(*losses):
+        assert abs(ah - bh) <= 1e-2 * abs(ah) and abs(al - bl) <= 1e-2 * abs(al), losses
 
 
 def test_image_slider_two_sided_step_matches_oracle(goldens):

@@ -1,5 +1,5 @@
 """One headline-size slider step (SD-XL 1024^2, B = 2, rank 4, synthetic weights) -> loss, LoRA gradient and updated
-parameters written to a .pt file.  Run under different SMI_GEMM / SMI_SIDE_STREAM settings to cross-check the kernel
+parameters written to a .pt file.  Run under different SMI_GEMM settings to cross-check the kernel
 generations against each other at the real shapes (tests/test_fullsize_gpu.py)."""
 import argparse, os, sys
 import torch
