@@ -234,6 +234,10 @@ int smi_sched_step(float* x, const float* eps, const float* noise, float c_x, fl
                    void* stream);
 
 /* ---- single-kernel entry points (used by the parity tests; same launchers the engine uses) ---------------- */
+/* Lends `bytes` of device memory at `ws` to the GEMM / conv launchers of THIS host thread as split-K scratch (fp32 partial
+ * slabs) until called again with NULL: with it, smi_op_gemm / smi_op_conv3x3 take the same split-K rule the engine's
+ * launches take (the engine lends a region of its own workspace per call); without it they never split. */
+int smi_op_gemm_scratch(void* ws, size_t bytes);
 int smi_op_gemm(int dtype, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
                 const void* res, const float* lora_xa, const float* lora_up, int lora_r, float lora_scale,
                 int out_f32, void* stream);

@@ -89,6 +89,7 @@ _SIGS = {
     "smi_clip_adamw": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p,
                                                                                     C.c_void_p]),
     "smi_sched_step": (C.c_int, [C.c_void_p] * 3 + [C.c_float] * 3 + [C.c_int64, C.c_void_p]),
+    "smi_op_gemm_scratch": (C.c_int, [C.c_void_p, C.c_size_t]),
     "smi_op_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "smi_op_gemm_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

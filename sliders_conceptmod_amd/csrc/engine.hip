@@ -204,6 +204,8 @@ struct smi_engine {
   std::vector<WgradJob> wjobs;
   std::vector<WgradJob> wjobs_uploaded;  // what the device table holds (same addresses every step of a plan: no re-upload)
   WgradJob* wjobs_dev = nullptr;
+  static constexpr size_t SPLITK_WS_BYTES = (size_t)384 * 128 * 128 * sizeof(float);  // 25 MB
+  void* splitk_ws = nullptr;
   size_t wjobs_cap = 0;
   std::vector<const void*> pinned;
   WgradJob& push_wjob(const void* X, int64_t ldx, const float* P, int64_t ldp, float* dW, int64_t so_r, int64_t so_k,
@@ -842,6 +844,7 @@ struct smi_engine {
     build_kv_group();
     finish_lora();
     gscale = (float*)pack_alloc((3 * MAXS + 258) * sizeof(float));  // + [2 MAXS..): min, 1/min, min / scale_j (DoRA)
+    splitk_ws = pack_alloc(SPLITK_WS_BYTES);  // fp32 slabs of the split-K launches (gemm.hip: S x tiles <= 384 tiles)
     wjobs_cap = 11 * (sites.size() + 8);  // a conv site pushes 10 jobs (d_up + one d_down job per filter tap)
     wjobs_dev = (WgradJob*)pack_alloc(wjobs_cap * sizeof(WgradJob));
     for (size_t i = 0; i < sites.size(); ++i)
@@ -2385,6 +2388,14 @@ int smi_engine_stats(const smi_engine* e, int64_t out[4]) {
   return 0;
 }
 
+namespace {
+// the engine lends its split-K scratch to launch_gemm for the duration of one call on this host thread
+struct GemmScratchScope {
+  GemmScratchScope(void* ws, size_t bytes) { smi::set_gemm_scratch(ws, bytes); }
+  ~GemmScratchScope() { smi::set_gemm_scratch(nullptr, 0); }
+};
+}  // namespace
+
 int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* sample, float timestep, const void* ctx,
                              const void* text_embeds, const float* time_ids, const float* lora_down_flat,
                              const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out) {
@@ -2398,6 +2409,7 @@ int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* s
   e->lora_down = lora_down_flat;
   e->lora_up = lora_up_flat;
   e->mult = (lora_down_flat && lora_up_flat && n_adapted > 0) ? multiplier : 0.f;
+  GemmScratchScope scratch(e->splitk_ws, smi_engine::SPLITK_WS_BYTES);
   return e->forward(n, n_adapted, sample, timestep, ctx, text_embeds, time_ids, save_for_backward != 0, eps_out);
 }
 
@@ -2413,6 +2425,7 @@ int smi_unet_backward(smi_engine* e, const float* d_eps, float* d_lora_down_flat
   SMI_CHECK(e && d_eps && d_lora_down_flat && d_lora_up_flat, "NULL argument");
   SMI_CHECK(!e->is_vae && !e->is_clip, "this engine is a VAE / CLIP encoder: it has no backward");
   e->err = false;
+  GemmScratchScope scratch(e->splitk_ws, smi_engine::SPLITK_WS_BYTES);
   return e->backward(d_eps, d_lora_down_flat, d_lora_up_flat);
 }
 
@@ -2471,6 +2484,10 @@ int smi_sched_step(float* x, const float* eps, const float* noise, float c_x, fl
 }
 
 // ---- single-kernel entry points for the parity tests -----------------------------------------------------------
+int smi_op_gemm_scratch(void* ws, size_t bytes) {
+  smi::set_gemm_scratch(ws, bytes);
+  return 0;
+}
 int smi_op_gemm(int dtype, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
                 const void* res, const float* lora_xa, const float* lora_up, int lora_r, float lora_scale,
                 int out_f32, void* stream) {

@@ -292,6 +292,66 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const T* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// split-K finish: C[m, n] = sum_s slab[s][m][n] (slices in ascending order: deterministic) + the GEMM epilogue
+// (bias, row vector, rank-r delta as the canonical fmaf chain of smi_common.h, residual), one rounding at the store.
+// One thread = 4 consecutive columns of one row.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(GemmParams p, const float* __restrict__ slab, int nsplit) {
+  const int n4 = p.N >> 2;
+  const int64_t total = (int64_t)p.M * n4;
+  const int64_t plane = (int64_t)p.M * p.N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx - (int64_t)m * n4) * 4;
+    const float* sp = slab + (int64_t)m * p.N + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+    for (int s = 1; s < nsplit; ++s) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(sp + s * plane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += w[j];
+    }
+    if (p.bias) {
+      Pack4<T> b;
+      b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.bias) + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+    }
+    if (p.rowvec) {
+      Pack4<T> b;
+      b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.rowvec) + (int64_t)(m / p.rows_per_vec) * p.N + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+    }
+    if (p.lora_r > 0 && m >= p.lora_row0) {
+      const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
+        const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
+        float d = 0.f;
+        for (int r = 0; r < p.lora_r; ++r) d = __builtin_fmaf(xr[r], up[r * p.up_sq], d);
+        v[j] = __builtin_fmaf(d, p.lora_scale, v[j]);
+      }
+    }
+    if (p.res) {
+      Pack4<T> b;
+      b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
+    }
+    if (p.out_f32) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = v;
+    } else {
+      Pack4<T> o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.e[j] = from_f<T>(v[j]);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) = o.u;
+    }
+  }
+}
+
 }  // namespace
 
 bool gemm2_supported(const GemmParams& p);
@@ -307,7 +367,7 @@ static int gemm_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SMI_GEMM");
-    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : (!strcmp(e, "64w") ? 11 : (!strcmp(e, "5ph") ? 12 : (!strcmp(e, "no5ph") ? 13 : (!strcmp(e, "160w") ? 14 : 0))))))))))))));
+    mode = !e ? 0 : (!strcmp(e, "v1") ? 3 : (!strcmp(e, "128") ? 1 : (!strcmp(e, "256") ? 2 : (!strcmp(e, "convv1") ? 4 : (!strcmp(e, "64") ? 5 : (!strcmp(e, "8ph") ? 6 : (!strcmp(e, "no8ph") ? 7 : (!strcmp(e, "160") ? 8 : (!strcmp(e, "8w") ? 9 : (!strcmp(e, "no8w") ? 10 : (!strcmp(e, "64w") ? 11 : (!strcmp(e, "5ph") ? 12 : (!strcmp(e, "no5ph") ? 13 : (!strcmp(e, "160w") ? 14 : (!strcmp(e, "64x160") ? 15 : 0)))))))))))))));
   }
   return mode;
 }
@@ -390,7 +450,8 @@ bool tune_enabled() {
   }
   return on == 1;
 }
-// candidate codes: 0 = heuristic, 1 = v2 128x128 (8 waves), 2 = v2 256x128, 4 = v2 128x160, 7 = v2 64x128,
+// candidate codes: 0 = heuristic, 1 = v2 128x128 (8 waves), 2 = v2 256x128, 4 = v2 128x160, 7 = v2 64x128, 10 = v2
+// 128x160 with 8 waves, 12 = v2 64x160,
 // 100 = v3 8-phase, 200 = v4 256x320 persistent
 int launch_candidate(const GemmParams& p, int cand, hipStream_t stream) {
   if (cand == 200 && gemm4_supported(p)) return launch_gemm4(p, stream);
@@ -416,7 +477,7 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
   auto& cache = tune_cache();
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
-  int cands[10], nc = 0;
+  int cands[14], nc = 0;
   cands[nc++] = 0;
   const bool plain_conv = p.conv && p.stride == 1 && !p.upsample && !p.transposed;
   if (!p.conv || plain_conv) {
@@ -424,7 +485,10 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
     if ((int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 128) cands[nc++] = 2;
     if (p.N % 160 == 0 && (!p.geglu_out || p.N % 320 == 0)) cands[nc++] = 4;
     if (gemm3_supported(p) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) cands[nc++] = 100;
-    if (!p.conv && (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) <= 512) cands[nc++] = 7;  // 64 x 128 tiles for small grids
+    if ((int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) <= 512) cands[nc++] = 7;  // 64 x 128 tiles for small grids
+    // 64 x 160 tiles (4 waves of 32 x 80) where 128 x 160 tiles leave CUs idle
+    if (!p.geglu_out && p.N % 160 == 0 && (int64_t)cdiv(p.M, 128) * (p.N / 160) <= 256) cands[nc++] = 12;
+    if (!p.geglu_out && p.N % 160 == 0 && p.K >= 1280 && (int64_t)cdiv(p.M, 128) * (p.N / 160) <= 128) cands[nc++] = 11;
     if (gemm4_supported(p) && (int64_t)(p.M / 256) * (p.N / 320) >= 128) cands[nc++] = 200;
     // about one 128 x 160 tile per CU: the eight-wave form of that tile
     if (!p.geglu_out && p.N % 160 == 0 && p.N % 8 == 0 && (int64_t)cdiv(p.M, 128) * (p.N / 160) <= 512) cands[nc++] = 10;
@@ -484,9 +548,74 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-K by RULE for grids that leave most CUs idle behind a long K loop: SD-1.x at batch 1-4 (conv 128 x 1280 x 11520:
+// ten 128 x 128 tiles on 256 CUs, 180 K-tiles each), the deepest UNet level of the pre-roll, the time-embedding MLPs.
+// The slice count is a function of the shape alone -- never of a timing -- so results stay reproducible run to run, and
+// the rule sits in front of every generation override: each slice accumulates its K-tiles in ascending order on the
+// gemm2 kernels (bit-identical among themselves) and one finish kernel adds the slices in order and applies the epilogue,
+// so the SMI_GEMM overrides still agree bit for bit with the default selection.
+//   tiles = 128 x 128 output tiles, nk = 64-deep K-tiles:  tiles <= 160, nk >= 16
+//   S = largest power of two <= min(16, 384 / tiles, nk / 4), limited by the scratch the caller provides
+// SMI_GEMM_SPLITK=0 turns the rule off.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+thread_local void* t_scratch = nullptr;
+thread_local size_t t_scratch_bytes = 0;
+int splitk_slices(const GemmParams& p) {
+  static const bool on = []() { const char* e = getenv("SMI_GEMM_SPLITK"); return !(e && !strcmp(e, "0")); }();
+  if (!on || !t_scratch || p.geglu_out || p.ksplit || !gemm2_supported(p) || p.N % 4 != 0) return 1;
+  const int64_t tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
+  const int nk = cdiv(p.K, 64);
+  if (tiles > 160 || nk < 16) return 1;
+  int64_t lim = 16;
+  if (384 / tiles < lim) lim = 384 / tiles;
+  if (nk / 4 < lim) lim = nk / 4;
+  const int64_t fit = (int64_t)(t_scratch_bytes / ((size_t)p.M * p.N * sizeof(float)));
+  if (fit < lim) lim = fit;
+  int s = 1;
+  while (2 * s <= lim) s *= 2;
+  return s;
+}
+int launch_splitk(const GemmParams& p, int S, hipStream_t stream) {
+  if (p.conv) {
+    SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
+              "conv: inconsistent geometry");
+  }
+  GemmParams q = p;  // the slices: plain accumulation into fp32 slabs [S][M][N]
+  q.C = t_scratch;
+  q.ldc = p.N;
+  q.out_f32 = 1;
+  q.bias = q.res = q.rowvec = nullptr;
+  q.lora_r = 0;
+  q.lora_xa = q.lora_up = nullptr;
+  q.ksplit = S;
+  // 64 x 128 tiles (4 waves) while that still leaves CUs idle, else the 128 x 128 eight-wave tile
+  const int64_t wg64 = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * S;
+  if (launch_gemm2(q, wg64 <= 512 ? 7 : 5, stream) != 0) return -1;
+  const int64_t total = (int64_t)p.M * (p.N / 4);
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  if (p.dtype == DT_F16)
+    hipLaunchKernelGGL(splitk_finish_kernel<f16>, dim3(grid), dim3(256), 0, stream, p, (const float*)t_scratch, S);
+  else
+    hipLaunchKernelGGL(splitk_finish_kernel<bf16>, dim3(grid), dim3(256), 0, stream, p, (const float*)t_scratch, S);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+void set_gemm_scratch(void* ws, size_t bytes) {
+  t_scratch = ws;
+  t_scratch_bytes = ws ? bytes : 0;
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
   SMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   SMI_CHECK(!p.geglu_out || gemm_geglu_supported(p), "gemm: fused GEGLU not available for this shape/layout");
+  if (gemm_mode() != 3) {
+    const int S = splitk_slices(p);
+    if (S > 1) return launch_splitk(p, S, stream);
+  }
   // One 128 x 160 tile per CU with a long K (the 4096-row backward GEMMs and convs): the eight-wave tile with the
   // four-stage deep-prefetch loop, by RULE and not by tuning -- the tuner times candidates back to back with their
   // operands hot in L2 / the Infinity Cache, where prefetch depth buys nothing (121 vs 120 us at 4096 x 1280 x 10240);
@@ -494,21 +623,25 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   // 193 -> 160 us; measured in the step, A/B on one device).  Bit-identical to every other form.  SMI_GEMM_DEEP=0 turns
   // the rule off, SMI_GEMM_DEEP_K moves the K threshold.
   if (gemm_mode() == 0) {
-    static int deep = -1, deep_k = 1280;
+    // grids of at most `small_grid` 128 x 160 tiles (half the CUs idle: SD-1.x at batch 1-2, the deepest UNet level) are
+    // left to the tuner, which can give them 64-row tiles (twice the workgroups) -- or this same deep form (candidate 11)
+    static int deep = -1, deep_k = 1280, small_grid = 128;
     if (deep < 0) {
       const char* e = getenv("SMI_GEMM_DEEP");
       deep = (e && !strcmp(e, "0")) ? 0 : 1;
       if (const char* k = getenv("SMI_GEMM_DEEP_K")) deep_k = atoi(k);
+      if (const char* k = getenv("SMI_GEMM_SMALL_GRID")) small_grid = atoi(k);
     }
     if (deep && gemm2_supported(p) && !p.geglu_out && p.N % 160 == 0 && p.K >= deep_k &&
-        (int64_t)cdiv(p.M, 128) * (p.N / 160) <= 320 && (!p.conv || (p.stride == 1 && !p.upsample && !p.transposed))) {
+        (int64_t)cdiv(p.M, 128) * (p.N / 160) <= 320 && (int64_t)cdiv(p.M, 128) * (p.N / 160) > small_grid &&
+        (!p.conv || (p.stride == 1 && !p.upsample && !p.transposed))) {
       if (p.conv) {
         SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout, "conv: inconsistent geometry");
       }
       return launch_gemm2(p, 11, stream);
     }
   }
-  if (gemm_mode() == 0 && tune_enabled() && gemm2_supported(p) && (int64_t)p.M * p.N >= (1 << 20)) {
+  if (gemm_mode() == 0 && tune_enabled() && gemm2_supported(p) && (int64_t)p.M * p.N >= (1 << 17)) {
     if (p.conv) {
       SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
                 "conv: inconsistent geometry");
@@ -520,6 +653,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   // v4 (256x320 tile, persistent): SMI_GEMM=5ph forces it wherever its layout rules hold
   if (gemm_mode() == 12 && gemm4_supported(p)) return launch_gemm4(p, stream);
   if (gemm_mode() == 14 && gemm2_supported(p) && !p.geglu_out && p.N % 160 == 0) return launch_gemm2(p, 10, stream);
+  if (gemm_mode() == 15 && gemm2_supported(p) && !p.geglu_out && p.N % 160 == 0) return launch_gemm2(p, 12, stream);
   if ((gemm_mode() == 6 || ((gemm_mode() == 0 || gemm_mode() == 10) && gemm3_wanted(p))) && gemm3_supported(p))
     return launch_gemm3(p, stream);
   if (gemm_mode() != 3 && gemm2_supported(p) && (!p.conv || gemm_mode() != 4)) {

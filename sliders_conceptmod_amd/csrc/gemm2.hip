@@ -76,6 +76,14 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
+  // split-K: the grid holds ksplit workgroups per output tile (adjacent after the remap); slice s owns a contiguous range
+  // of K-tiles and writes fp32 partials to its own slab
+  const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+  int kslice = 0;
+  if (nsplit > 1) {
+    kslice = wg % nsplit;
+    wg /= nsplit;
+  }
   // grouped rasterisation: consecutive workgroups (= the ones co-resident on one XCD after the remap above) sweep a
   // band of GW column tiles before moving down a row tile, so the 32-64 tiles sharing an L2 form a ~8x8 patch
   // (8 + 8 operand panels per K-step instead of 1 + 64 for a wide-N GEMM walked row-major)
@@ -93,6 +101,9 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
     return geglu ? (nl < BN / 2 ? (bn0 >> 1) + nl : nhalf + (bn0 >> 1) + nl - BN / 2) : bn0 + nl;
   };
 
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kbase = (int)((int64_t)kslice * nk_all / nsplit);                    // first K-tile of this slice
+  const int nk = (int)((int64_t)(kslice + 1) * nk_all / nsplit) - kbase;         // its K-tile count (all of K unsplit)
   const unsigned char* zero = g_zero_page;
   const T* Ap = reinterpret_cast<const T*>(p.A);
   const T* Wp = reinterpret_cast<const T*>(p.W);
@@ -161,13 +172,13 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
     const bool ok = !CONV && a_ptr[j] != nullptr;
-    a_src[j] = ok ? a_ptr[j] + a_chunk[j] * 8 : reinterpret_cast<const T*>(zero);
+    a_src[j] = ok ? a_ptr[j] + a_chunk[j] * 8 + (int64_t)kbase * BK : reinterpret_cast<const T*>(zero);
     a_step[j] = ok ? BK : 0;
   }
 #pragma unroll
   for (int j = 0; j < B_INSTR; ++j) {
     const bool ok = w_ptr[j] != nullptr;
-    w_src[j] = ok ? w_ptr[j] + w_chunk[j] * 8 : reinterpret_cast<const T*>(zero);
+    w_src[j] = ok ? w_ptr[j] + w_chunk[j] * 8 + (int64_t)kbase * BK : reinterpret_cast<const T*>(zero);
     w_step[j] = ok ? BK : 0;
   }
   auto stage_inc = [&](int buf) {
@@ -191,7 +202,7 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
     }
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + BM * BK * 2;
-    const int k0 = kt * BK;
+    const int k0 = (kbase + kt) * BK;
     if (CONV) {
       const int tap = k0 / p.Cin;
       const int c0 = k0 - tap * p.Cin;
@@ -253,7 +264,6 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
 #pragma unroll
     for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
   const int fr = lane & 15;
   const int fq = lane >> 4;
 
@@ -516,7 +526,7 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
         }
       }
       if (p.out_f32) {
-        float* op = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+        float* op = reinterpret_cast<float*>(p.C) + ((int64_t)kslice * p.M + m) * p.ldc + n;  // (kslice = 0 unsplit)
         *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
         if (full) *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
       } else if (stage_out && full) {
@@ -601,7 +611,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN) * (p.ksplit > 1 ? p.ksplit : 1);
   hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM, NL, DEEP>), dim3(grid), dim3(NW * 64), SMEM, stream, p);
   SMI_HIP(hipGetLastError());
   return 0;
@@ -661,7 +671,11 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
   if (variant == 3) wm = 1;
   if (variant == 4 && ok160) { wm = 2; nl = 1; }
   if (variant == 5) { wm = 2; nl = 2; }
-  if (variant == 7 && !p.conv) { wm = 1; nl = 2; }  // 64 x 128 tile, 4 waves of 32 x 64: twice the tiles for small grids
+  if (variant == 7) { wm = 1; nl = 2; }  // 64 x 128 tile, 4 waves of 32 x 64: twice the tiles for small grids
+  if (variant == 12 && ok160 && !p.geglu_out) {  // 64 x 160 tile, 4 waves of 32 x 80: small grids with N % 160 == 0
+    if (p.dtype == DT_F16) return p.conv ? launch_t<f16, true, 1, 3>(p, stream) : launch_t<f16, false, 1, 3>(p, stream);
+    return p.conv ? launch_t<bf16, true, 1, 3>(p, stream) : launch_t<bf16, false, 1, 3>(p, stream);
+  }
   if ((variant == 10 || variant == 11) && ok160 && !p.geglu_out) {  // 128 x 160 tile with eight waves of 32 x 80 (NL = 3)
     if (variant == 11) {  // ... with the deep-prefetch loop
       if (p.dtype == DT_F16)
@@ -674,7 +688,7 @@ int launch_gemm2(const GemmParams& p, int variant, hipStream_t stream) {
 #define GO(TT_, CV, W_, NL_) return launch_t<TT_, CV, W_, NL_>(p, stream)
 #define PICK(TT_, CV)                            \
   do {                                           \
-    if (nl == 2 && wm == 1 && !CV) GO(TT_, false, 1, 2); \
+    if (nl == 2 && wm == 1) GO(TT_, CV, 1, 2);   \
     if (nl == 2) GO(TT_, CV, 2, 2);              \
     if (nl) GO(TT_, CV, 2, 1);                   \
     if (wm == 4) GO(TT_, CV, 4, 0);              \

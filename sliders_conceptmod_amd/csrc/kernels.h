@@ -53,8 +53,15 @@ struct GemmParams {
   int pad = 1;         // 1 everywhere in the UNet; 0 for the VAE encoder's (0,1,0,1)-padded stride-2 downsampler
   int upsample = 0;    // nearest-2x upsample of the input folded into the gather
   int transposed = 0;  // gradient of a strided conv: out = (in + 1 - k) / stride
+  // split-K (internal to launch_gemm, gemm2 kernels only): the workgroups of slice s accumulate K-tiles
+  // [s nk / ksplit, (s + 1) nk / ksplit) and store fp32 partials to C + s * M * ldc (out_f32 form, no epilogue)
+  int ksplit = 0;
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
+// Scratch for split-K partial sums (fp32 slabs), set by whoever owns memory (the engine, per call; tests through
+// smi_op_gemm_scratch) for the calling host thread; without it launch_gemm never splits.  Launches that use it are ordered
+// on their stream, so one buffer serves every launch of a pass.
+void set_gemm_scratch(void* ws, size_t bytes);
 bool gemm_geglu_supported(const GemmParams& p);  // can launch_gemm take p.geglu_out?
 
 // direct 3x3 conv for tiny channel counts (conv_in: Cin=4; conv_out: Cout=4 and their gradients)

@@ -89,6 +89,58 @@ def test_gemm_full_epilogue(lib, dt, r):
     torch.testing.assert_close(c32, a.float() @ w.float().t() + bias.float(), rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_splitk_rule_gemm_and_conv(lib, dt):
+    """Split-K by rule (csrc/gemm.hip: few output tiles behind a long K loop -- SD-1.x at batch 1-2, the deepest UNet level,
+    the time-embedding MLPs): fp32 slabs per K-slice + one finish kernel with the full epilogue.  Against fp32 torch on the
+    same rounded inputs, with and without the scratch (the unsplit kernels), bit-reproducible run to run, every epilogue
+    term, dense and conv (plain, stride 2, transposed gradient)."""
+    ws = torch.empty(384 * 128 * 128, device="cuda", dtype=torch.float32)
+    try:
+        for (M, N, K, r) in ((128, 1280, 11520, 4), (512, 1280, 10240, 0), (16, 1280, 1280, 0), (2048, 640, 5120, 8),
+                             (136, 324, 2048, 0)):
+            a, w = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+            bias, res = rnd(N, dt=dt, seed=3), rnd(M, N, dt=dt, seed=4)
+            xa = torch.randn(M, max(r, 1), device="cuda") if r else None
+            up = torch.randn(N, max(r, 1), device="cuda") * 0.1 if r else None
+            ref = a.float() @ w.float().t() + bias.float() + res.float() + (0.375 * (xa @ up.t()) if r else 0.0)
+            outs = []
+            for scratch in (True, False, True):
+                chk(lib, lib.smi_op_gemm_scratch(P(ws) if scratch else None, ws.numel() * 4 if scratch else 0))
+                c = torch.empty(M, N, device="cuda", dtype=dt)
+                chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa), P(up), r, 0.375, 0,
+                                         None))
+                close(c, ref, dt, what=f"gemm {M}x{N}x{K} scratch={scratch}")
+                outs.append(c)
+            assert torch.equal(outs[0], outs[2]), "split-K result differs between two runs"
+            chk(lib, lib.smi_op_gemm_scratch(P(ws), ws.numel() * 4))
+            c32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+            chk(lib, lib.smi_op_gemm(dcode(dt), P(a), P(w), P(c32), M, N, K, P(bias), None, None, None, 0, 0.0, 1, None))
+            torch.testing.assert_close(c32, a.float() @ w.float().t() + bias.float(), rtol=2e-5, atol=5e-4)
+        for (nb, H, Cin, Cout) in ((2, 8, 1280, 1280), (1, 16, 1280, 640), (2, 8, 2560, 1280)):
+            x = rnd(nb, H, H, Cin, dt=dt, seed=1)
+            w = rnd(Cout, Cin, 3, 3, dt=dt, scale=(9 * Cin) ** -0.5, seed=2)
+            b = rnd(Cout, dt=dt, seed=3)
+            xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+            for stride in (1, 2):
+                Ho = (H + 1) // 2 if stride == 2 else H
+                ref = F.conv2d(xr, w.float(), b.float(), stride=stride, padding=1)
+                gy = rnd(nb, Ho, Ho, Cout, dt=dt, seed=5)
+                (gref,) = torch.autograd.grad(ref, xr, gy.float().permute(0, 3, 1, 2))
+                for scratch in (True, False):
+                    chk(lib, lib.smi_op_gemm_scratch(P(ws) if scratch else None, ws.numel() * 4 if scratch else 0))
+                    y = torch.empty(nb, Ho, Ho, Cout, device="cuda", dtype=dt)
+                    chk(lib, lib.smi_op_conv3x3(dcode(dt), P(x), P(pack_fwd(w)), P(b), P(y), nb, H, H, Cin, Cout, stride, 0,
+                                                0, Ho, Ho, None))
+                    close(y.permute(0, 3, 1, 2), ref, dt, what=f"conv s{stride} scratch={scratch}")
+                    gx = torch.empty(nb, H, H, Cin, device="cuda", dtype=dt)
+                    chk(lib, lib.smi_op_conv3x3(dcode(dt), P(gy), P(pack_grad(w, stride == 1)), None, P(gx), nb, Ho, Ho,
+                                                Cout, Cin, stride, 0, 1 if stride == 2 else 0, H, H, None))
+                    close(gx.permute(0, 3, 1, 2), gref, dt, mult=8, what=f"conv s{stride} dX scratch={scratch}")
+    finally:
+        chk(lib, lib.smi_op_gemm_scratch(None, 0))
+
+
 # ---- shapes with >= 512 tiles of 256 x 256 run on the 8-phase kernel (gemm3.hip); the smaller ones above on gemm2.hip
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", [(8192, 4096, 64), (8192, 4096, 192), (8200, 4104, 320), (16384, 2048, 1280)])
@@ -347,7 +399,7 @@ def test_gemm_generations_are_bit_identical_per_epilogue_class():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("128", "256", "160", "160w", "64", "8ph", "5ph", ""):
+    for mode in ("128", "256", "160", "160w", "64", "64w", "64x160", "8ph", "5ph", ""):
         env = dict(os.environ)
         env.pop("SMI_GEMM", None)
         if mode:

@@ -26,8 +26,19 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     rn = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc)
     out = {}
+    ws = torch.empty(384 * 128 * 128, device="cuda", dtype=torch.float32)  # split-K scratch, as the engine lends it
+    _native.check(lib.smi_op_gemm_scratch(P(ws), ws.numel() * 4), "scratch")
     for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
         tag = "f16" if code == 0 else "bf16"
+        # shapes under the split-K rule: the override must not change their bits either
+        for M, N, K, r in ((128, 1280, 11520, 4), (512, 1280, 5120, 0)):
+            a, w = rn(M, K).to(dt), rn(N, K, sc=K ** -0.5).to(dt)
+            bias, res = rn(N).to(dt), rn(M, N).to(dt)
+            xa, up = rn(M, max(r, 1)), rn(N, max(r, 1))
+            c = torch.empty(M, N, device="cuda", dtype=dt)
+            _native.check(lib.smi_op_gemm(code, P(a), P(w), P(c), M, N, K, P(bias), P(res), P(xa) if r else None,
+                                          P(up) if r else None, r, 0.25, 0, None), "gemm")
+            out[f"{tag}/splitk/{M}x{N}x{K}r{r}"] = dig(c)
         for M, N, K, r in ((4096, 1280, 1280, 4), (16384, 3840, 1280, 4), (2048, 640, 2560, 8)):
             a, w = rn(M, K).to(dt), rn(N, K, sc=K ** -0.5).to(dt)
             bias, res = rn(N).to(dt), rn(M, N).to(dt)
