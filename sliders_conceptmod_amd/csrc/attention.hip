@@ -168,8 +168,10 @@ template <typename T, int DP, bool EX>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
-  __shared__ __attribute__((aligned(16))) T Ks[TK * S::LDN];
-  __shared__ __attribute__((aligned(16))) T Vs[TK * S::LDV];
+  // two LDS stages: tile t + 1 is written while tile t is being read, so ONE barrier per key tile orders both the
+  // "everyone is done with stage s" and the "stage s ^ 1 is complete" edges (it was two barriers on one stage)
+  __shared__ __attribute__((aligned(16))) T Ks2[2][TK * S::LDN];
+  __shared__ __attribute__((aligned(16))) T Vs2[2][TK * S::LDV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, h2 = lane >> 5;
@@ -207,15 +209,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   u32x4 rk[S::NIT], rv[S::NIT];
   S::load(rk, rK, 0, p.Nk, p.ldk, col0, p.D, tid);
   S::load(rv, rV, 0, p.Nk, p.ldv, col0, p.D, tid);
+  S::store_nat(rk, Ks2[0], tid);
+  S::store_ld(rv, Vs2[0], S::LDV, tid);
+  if (ntiles > 1) {
+    S::load(rk, rK, TK, p.Nk, p.ldk, col0, p.D, tid);
+    S::load(rv, rV, TK, p.Nk, p.ldv, col0, p.D, tid);
+  }
+  __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * TK;
-    __syncthreads();  // previous tile fully consumed
-    S::store_nat(rk, Ks, tid);
-    S::store_ld(rv, Vs, S::LDV, tid);
-    __syncthreads();
-    if (kt + 1 < ntiles) {
-      S::load(rk, rK, k0 + TK, p.Nk, p.ldk, col0, p.D, tid);
-      S::load(rv, rV, k0 + TK, p.Nk, p.ldv, col0, p.D, tid);
+    const T* Ks = Ks2[kt & 1];
+    const T* Vs = Vs2[kt & 1];
+    if (kt + 1 < ntiles) {  // tile kt + 1 (in registers since the previous iteration) into the other stage, kt + 2 on its way
+      S::store_nat(rk, Ks2[(kt + 1) & 1], tid);
+      S::store_ld(rv, Vs2[(kt + 1) & 1], S::LDV, tid);
+      if (kt + 2 < ntiles) {
+        S::load(rk, rK, k0 + 2 * TK, p.Nk, p.ldk, col0, p.D, tid);
+        S::load(rv, rV, k0 + 2 * TK, p.Nk, p.ldv, col0, p.D, tid);
+      }
     }
 
     f32x16 st[2];
@@ -298,6 +309,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         }
         l4 = Sum4<T>::add8(pf, l4);
       }
+    __syncthreads();  // every wave is done with stage kt & 1, and stage (kt + 1) & 1 is complete
   }
 
   const float l_tot = halves_sum(l4[0]);
