@@ -37,7 +37,8 @@ def ids_for(cfg, n=3, seed=0):
 
 
 @pytest.mark.parametrize("which", ["tiny_quick_gelu", "tiny_gelu_proj", "clip_l", "open_clip_bigg"])
-@pytest.mark.parametrize("dtype,bar", [(torch.float16, 3e-3), (torch.bfloat16, 2.5e-2)])
+# bars = 1.5 x measured (fp16: 1.49e-3 on OpenCLIP-bigG, <= 9.8e-4 on the others; bf16: 7.9e-3 on CLIP-L)
+@pytest.mark.parametrize("dtype,bar", [(torch.float16, 2.25e-3), (torch.bfloat16, 1.2e-2)])
 def test_clip_text_encoder_matches_oracle(which, dtype, bar):
     import sliders_conceptmod_amd.clip as PC
     if which == "tiny_quick_gelu":

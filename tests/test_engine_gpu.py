@@ -18,7 +18,7 @@ from oracle import slider_ref as R
 from oracle import unet_ref as OU
 
 CFGS = {"tiny_sd1x": OU.tiny_sd1x_config, "tiny_sdxl": OU.tiny_sdxl_config}
-LOOSE = {torch.float16: 3e-3, torch.bfloat16: 2.5e-2}   # vs pure fp32 oracle (measured ~1e-3 / ~8e-3)
+LOOSE = {torch.float16: 1.8e-3, torch.bfloat16: 1.4e-2}   # vs pure fp32 oracle: 1.5 x measured (1.17e-3 / 9.2e-3)
 
 
 def rel(a, b):
@@ -340,7 +340,7 @@ def test_c3lier_forward_and_gradients_match_oracle(model, method):
     (got * gy.cuda()).sum().backward()
     e = rel(got, ref)
     assert rel(ref, off) > 1e-2  # the conv adaptors move the output a lot more than the attention-only ones
-    assert e < LOOSE[dtype], e
+    assert e < 1.8e-3, e  # measured 8.1e-4 .. 1.19e-3 (1.5 x)
     by_kind = {}
     tot_num = tot_den = 0.0
     for lo, lp in zip(onet.unet_loras, pnet.unet_loras):
@@ -358,8 +358,9 @@ def test_c3lier_forward_and_gradients_match_oracle(model, method):
     glob = (tot_num / tot_den) ** 0.5
     print(f"{model} {method} c3lier: eps {e:.2e}, LoRA-grad global {glob:.2e}, by kind " +
           ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
-    assert glob < 8e-3, glob
-    assert all(v < 2.5e-2 for v in errs.values()), errs
+    # measured (fp16): global 2.28e-3 .. 2.41e-3, worst kind 3.23e-3 (attn1 on tiny SD-XL); bars = 1.5 x
+    assert glob < 3.6e-3, glob
+    assert all(v < 4.9e-3 for v in errs.values()), errs
 
 
 @pytest.mark.parametrize("model", list(CFGS))
@@ -406,7 +407,7 @@ def test_dora_forward_and_gradients_match_oracle(model, method):
         got = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
     (got * gy.cuda()).sum().backward()
     e = rel(got, ref)
-    assert rel(ref, off) > 1e-3 and e < LOOSE[dtype], (rel(ref, off), e)
+    assert rel(ref, off) > 1e-3 and e < 1.8e-3, (rel(ref, off), e)  # measured 8.3e-4 .. 1.18e-3
     errs = {}
     for what in ("down", "up", "scale"):
         num = den = 0.0
@@ -418,7 +419,7 @@ def test_dora_forward_and_gradients_match_oracle(model, method):
             den += float(b.norm() ** 2)
         errs[what] = (num / den) ** 0.5
     print(f"{model} {method} dora: eps {e:.2e}, grads " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
-    assert all(v < 8e-3 for v in errs.values()), errs
+    assert all(v < 5.3e-3 for v in errs.values()), errs  # measured 2.2e-3 .. 3.5e-3 (1.5 x)
     pnet.__exit__(None, None, None)
     with torch.no_grad():
         assert rel(pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample, off) < LOOSE[dtype]

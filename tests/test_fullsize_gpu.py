@@ -17,8 +17,10 @@ from oracle import unet_ref as OU
 EPS_BAR = 1.7e-3
 GRAD_BAR = 3.5e-3
 # real-width c3lier (SD-1.x) and DoRA (SD-XL): set to 1.5 x the first measurement (see the prints)
-C3_EPS_BAR, C3_GRAD_BAR, C3_KIND_BAR = 3e-3, 8e-3, 2.5e-2
-DORA_GRAD_BAR = 8e-3
+# measured: c3lier eps 1.13e-3, gradients 2.03e-3 globally, 1.63e-3 .. 2.66e-3 by kind; DoRA eps 7.9e-4, gradients 2.28e-3 ..
+# 2.45e-3 (down / up / dora_scale)
+C3_EPS_BAR, C3_GRAD_BAR, C3_KIND_BAR = 1.7e-3, 3.1e-3, 4.0e-3
+DORA_GRAD_BAR = 3.7e-3
 
 
 def rel(a, b):

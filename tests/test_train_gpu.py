@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 from oracle import unet_ref as OU
 
 CFGS = {"tiny_sd1x": OU.tiny_sd1x_config, "tiny_sdxl": OU.tiny_sdxl_config}
+SIGN_FLIP_BAR = 0.01  # measured 0.08 % (SD-1.x: 2 of 2560) / 0.29 % (SD-XL: 6 of 2048); share of lora_up elements whose sign may differ from the reference's Adam trajectory (see the test)
 
 
 class GoldenEncoder:
@@ -92,10 +93,22 @@ def test_cli_train_reproduces_reference_trajectory(goldens, tmp_path, model):
         if k.endswith("alpha"):
             continue
         assert float(sd[k].float().norm()) == pytest.approx(nrm, rel=2e-2, abs=2e-5), k
+    flips = total = 0
+    worst_cos = 1.0
     for k in [k for k in t if k.startswith(f"traj/{model}/sd/") and "lora_up" in k]:
         a, b = sd[k.split("/sd/")[1]].float().cpu().flatten(), t[k].float().flatten()
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        worst_cos = min(worst_cos, cos)
         assert cos > 0.97, f"{k}: cosine {cos:.4f}"
+        # lora_up starts at zero, so after a few sign-like Adam steps an element's SIGN is the sign of its first
+        # gradients: the share of elements whose sign differs from the reference run is the share of gradient elements
+        # that sit inside the 16-bit noise (the bar as a number)
+        flips += int((torch.sign(a) != torch.sign(b)).sum())
+        total += a.numel()
+    frac = flips / max(total, 1)
+    print(f"{model}: lora_up elements with a sign different from the reference trajectory: {flips} / {total} = "
+          f"{frac:.3%}; worst per-tensor cosine {worst_cos:.4f}")
+    assert frac < SIGN_FLIP_BAR, frac
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -186,7 +199,7 @@ def test_fused_step_matches_autograd_step(goldens, tmp_path, model):
     a, b = res
     rel = float((a - b).norm() / b.norm())
     print(f"{model}: fused vs autograd parameter distance {rel:.2e}; losses {losses}")
-    assert rel < 2e-3, f"fused vs autograd parameter distance {rel:.2e}"
+    assert rel < 1.1e-3, f"fused vs autograd parameter distance {rel:.2e}"  # measured 6.9e-4 (SD-1.x), 5.5e-6 (SD-XL)
     # the first loss is bit-equal; later ones see Adam's sign-like first updates amplify fp32-order differences (measured
     # 2e-3 on SD-1.x at lr 2e-3)
     assert losses[0][0] == pytest.approx(losses[1][0], rel=1e-5)
@@ -238,7 +251,7 @@ def test_image_slider_fused_step_matches_autograd_loop(tmp_path, xl):
         losses.append(net.training_losses)
     rel = float((res[1] - res[0]).norm() / res[0].norm())
     print(f"xl={xl}: fused vs autograd parameter distance {rel:.2e}")
-    assert rel < 2e-3, rel
+    assert rel < 3e-4, rel  # measured 1.07e-4 (SD-XL), 9.4e-5 (SD-1.x)
     for (ah, al), (bh, bl) in zip(*losses):
         assert abs(ah - bh) <= 1e-2 * abs(ah) and abs(al - bl) <= 1e-2 * abs(al), losses
 

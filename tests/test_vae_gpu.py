@@ -25,7 +25,8 @@ def pair(ocfg, dtype):
     return ov, pv.to("cuda", dtype).requires_grad_(False).eval()
 
 
-@pytest.mark.parametrize("dtype,bar", [(torch.float16, 3e-3), (torch.bfloat16, 2.5e-2)])
+# bars = 1.5 x measured (tiny VAE: fp16 1.53e-3, bf16 1.22e-2)
+@pytest.mark.parametrize("dtype,bar", [(torch.float16, 2.3e-3), (torch.bfloat16, 1.85e-2)])
 @pytest.mark.parametrize("size", [(64, 64), (96, 64)])
 def test_tiny_vae_moments_match_oracle(dtype, bar, size):
     ov, pv = pair(OV.tiny_vae_config(), dtype)
@@ -57,7 +58,7 @@ def test_real_sd_vae_encoder_256px_matches_oracle():
     dist = pv.encode(x.cuda()).latent_dist
     e_mean, e_lv = rel(dist.mean, ref[:, :4]), rel(dist.logvar, ref[:, 4:].clamp(-30, 20))
     print(f"SD VAE encoder 256px fp16: mean rel err {e_mean:.2e}, logvar rel err {e_lv:.2e}")
-    assert e_mean < 3e-3 and e_lv < 3e-3, (e_mean, e_lv)
+    assert e_mean < 2.4e-3 and e_lv < 2.4e-3, (e_mean, e_lv)  # measured 1.58e-3 / 1.47e-3 (1.5 x)
 
 
 def test_get_noisy_image_follows_the_reference_order():
