@@ -191,6 +191,16 @@ int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* s
                              const void* text_embeds, const float* time_ids, const float* lora_down_flat,
                              const float* lora_up_flat, float multiplier, int save_for_backward, float* eps_out);
 
+/* smi_unet_forward_batched with ONE ADAPTOR MULTIPLIER PER ADAPTED SAMPLE (`multipliers`: host array of n_adapted
+ * floats): the image-slider step runs the adaptor at +s on the `high` image and at -s on the `low` one
+ * (trainscripts/imagesliders/train_lora-scale-xl.py:317-381) -- with per-sample multipliers both sides share one UNet
+ * pass and one backward.  Implemented for Linear LoRA sites (attention projections, time_emb_proj, conv_shortcut); with
+ * conv (c3lier) or DoRA sites and unequal multipliers it returns an error (run the samples in separate passes).  Equal
+ * multipliers are exactly smi_unet_forward_batched. */
+int smi_unet_forward_multi(smi_engine* e, int n, int n_adapted, const float* sample, float timestep, const void* ctx,
+                           const void* text_embeds, const float* time_ids, const float* lora_down_flat,
+                           const float* lora_up_flat, const float* multipliers, int save_for_backward, float* eps_out);
+
 /* Backward of the last save_for_backward forward: accumulates (+=) d(loss)/d(lora_down), d(loss)/d(lora_up) into
  * the flat fp32 gradient buffers (same offsets as the parameters).  Activation gradients are propagated only as far
  * as the first adapted layer; no frozen-weight gradients exist (unet.requires_grad_(False), train_lora.py:69).

@@ -63,6 +63,8 @@ _SIGS = {
                              C.POINTER(C.c_void_p)]),
     "smi_unet_forward_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "smi_unet_forward_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "smi_destroy": (None, [C.c_void_p]),
     "smi_weights_bytes": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(LoraSiteC), C.c_int, C.POINTER(C.c_size_t)]),
     "smi_arena_bytes": (C.c_int, [C.POINTER(UNetConfigC), C.POINTER(LoraSiteC), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -278,11 +280,21 @@ class Engine:
         return self.stats()["tape_generation"] if self.handle else 0
 
     def forward(self, sample: torch.Tensor, timestep: float, ctx: torch.Tensor, text_embeds, time_ids, lora_down,
-                lora_up, multiplier: float, save: bool, n_adapted: Optional[int] = None) -> torch.Tensor:
-        """n_adapted: the LAST n_adapted samples get the LoRA delta and are differentiated (default: all)."""
+                lora_up, multiplier, save: bool, n_adapted: Optional[int] = None) -> torch.Tensor:
+        """n_adapted: the LAST n_adapted samples get the LoRA delta and are differentiated (default: all).
+        `multiplier`: one float, or a sequence of n_adapted floats (one adaptor multiplier per adapted sample,
+        smi_unet_forward_multi)."""
         n = sample.shape[0]
         na = min(n, self.batch_adapted) if n_adapted is None else n_adapted
         eps = torch.empty(sample.shape, dtype=torch.float32, device=sample.device)
+        if isinstance(multiplier, (list, tuple)):
+            if len(multiplier) != na:
+                raise SmiError(f"{len(multiplier)} multipliers for {na} adapted samples")
+            arr = (C.c_float * na)(*[float(m) for m in multiplier])
+            check(lib().smi_unet_forward_multi(self.handle, n, na, ptr(sample), float(timestep), ptr(ctx),
+                                               ptr(text_embeds), ptr(time_ids), ptr(lora_down), ptr(lora_up), arr,
+                                               int(save), ptr(eps)), "smi_unet_forward_multi")
+            return eps
         check(lib().smi_unet_forward_batched(self.handle, n, na, ptr(sample), float(timestep), ptr(ctx),
                                              ptr(text_embeds), ptr(time_ids), ptr(lora_down), ptr(lora_up),
                                              float(multiplier), int(save), ptr(eps)), "smi_unet_forward_batched")

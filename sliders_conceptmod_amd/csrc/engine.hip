@@ -206,6 +206,15 @@ struct smi_engine {
   WgradJob* wjobs_dev = nullptr;
   static constexpr size_t SPLITK_WS_BYTES = (size_t)384 * 128 * 128 * sizeof(float);  // 25 MB
   void* splitk_ws = nullptr;
+  // per-sample adaptor multipliers (smi_unet_forward_multi): sigma_i = m_i / m_ref per ADAPTED sample, applied to the rows
+  // of xa = x down^T (forward) and dxa = dy up (backward) -- every other use of the multiplier stays the scalar m_ref.
+  // Slot 0 serves the pass in flight, slot 1 keeps the saved pass's values for its backward.
+  float* samp_mult_dev = nullptr;  // [2][MAXS]
+  bool samp_on = false, bw_samp_on = false;
+  int n_conv_sites = 0;
+  const float* samp_ptr(bool bwd) const {
+    return (bwd ? bw_samp_on : samp_on) ? samp_mult_dev + (bwd ? MAXS : 0) : nullptr;
+  }
   size_t wjobs_cap = 0;
   std::vector<const void*> pinned;
   WgradJob& push_wjob(const void* X, int64_t ldx, const float* P, int64_t ldp, float* dW, int64_t so_r, int64_t so_k,
@@ -613,6 +622,7 @@ struct smi_engine {
     if (it == smap.end()) return;
     const smi_lora_site* s = it->second;
     site_used[s - sites.data()] = 1;
+    ++n_conv_sites;
     c.nsite = 1;
     c.rank = s->rank;
     c.scale = s->scale;
@@ -844,6 +854,7 @@ struct smi_engine {
     build_kv_group();
     finish_lora();
     gscale = (float*)pack_alloc((3 * MAXS + 258) * sizeof(float));  // + [2 MAXS..): min, 1/min, min / scale_j (DoRA)
+    samp_mult_dev = (float*)pack_alloc(2 * MAXS * sizeof(float));
     splitk_ws = pack_alloc(SPLITK_WS_BYTES);  // fp32 slabs of the split-K launches (gemm.hip: S x tiles <= 384 tiles)
     wjobs_cap = 11 * (sites.size() + 8);  // a conv site pushes 10 jobs (d_up + one d_down job per filter tap)
     wjobs_dev = (WgradJob*)pack_alloc(wjobs_cap * sizeof(WgradJob));
@@ -913,9 +924,14 @@ struct smi_engine {
       g.K = L.in;
       if (dry || lora_skinny_supported(g.A, g.lda, g.W, xa, g.ldc, g.M, g.N, g.K))
         RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0,
-             launch_lora_skinny(dtype, g.A, g.lda, g.W, xa, g.ldc, g.M, g.N, g.K, stream));
-      else
+             launch_lora_skinny(dtype, g.A, g.lda, g.W, xa, g.ldc, g.M, g.N, g.K, stream, samp_ptr(false),
+                                std::max(1, g.M / std::max(n_ad, 1))));
+      else {
         RUNP(SMI_PROF_LORA, 2.0 * g.M * rtot * g.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(g), 0) : 0, launch_gemm(g, stream)));
+        if (samp_on)
+          RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_row_scale_f32(xa, g.ldc, g.M, g.N, samp_ptr(false),
+                                                             std::max(1, g.M / std::max(n_ad, 1)), stream));
+      }
     }
     GemmParams p;
     p.dtype = dtype;
@@ -1020,9 +1036,14 @@ struct smi_engine {
         g.K = L->out;
         if (dry || lora_skinny_supported(g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K))
           RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0,
-               launch_lora_skinny(dtype, g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K, stream));
-        else
+               launch_lora_skinny(dtype, g.A, g.lda, g.W, dxa, g.ldc, g.M, g.N, g.K, stream, samp_ptr(true),
+                                  std::max(1, M / std::max(n_ad, 1))));
+        else {
           RUNP(SMI_PROF_LORA, 2.0 * M * rtot * cs, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(g), 0) : 0, launch_gemm(g, stream)));
+          if (bw_samp_on)
+            RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_row_scale_f32(dxa, g.ldc, g.M, g.N, samp_ptr(true),
+                                                               std::max(1, M / std::max(n_ad, 1)), stream));
+        }
       }
       // deferred (see `wjobs`): d(up)[n][q] += lscale/S * sum_m dy[m][n] * xa[m][seg(n)*r + q]  for all segments,
       //                         d(down)[q'][k] += lscale/S * sum_m dxa[m][q'] * x[m][k]       (q' over the r_tot rows)
@@ -1963,6 +1984,7 @@ struct smi_engine {
       bw_down = lora_down;
       bw_up = lora_up;
       bw_mult = mult;
+      bw_samp_on = samp_on;
       tape_valid = true;
     }
     saving = false;
@@ -2411,6 +2433,37 @@ int smi_unet_forward_batched(smi_engine* e, int n, int n_adapted, const float* s
   e->mult = (lora_down_flat && lora_up_flat && n_adapted > 0) ? multiplier : 0.f;
   GemmScratchScope scratch(e->splitk_ws, smi_engine::SPLITK_WS_BYTES);
   return e->forward(n, n_adapted, sample, timestep, ctx, text_embeds, time_ids, save_for_backward != 0, eps_out);
+}
+
+int smi_unet_forward_multi(smi_engine* e, int n, int n_adapted, const float* sample, float timestep, const void* ctx,
+                           const void* text_embeds, const float* time_ids, const float* lora_down_flat,
+                           const float* lora_up_flat, const float* multipliers, int save_for_backward, float* eps_out) {
+  SMI_CHECK(e && multipliers, "NULL argument");
+  SMI_CHECK(n_adapted >= 1 && n_adapted <= smi_engine::MAXS, "per-sample multipliers: 1..%d adapted samples", smi_engine::MAXS);
+  float mref = 0.f;
+  bool same = true;
+  for (int i = 0; i < n_adapted; ++i) {
+    if (fabsf(multipliers[i]) > mref) mref = fabsf(multipliers[i]);
+    same = same && multipliers[i] == multipliers[0];
+  }
+  if (same || mref == 0.f)
+    return smi_unet_forward_batched(e, n, n_adapted, sample, timestep, ctx, text_embeds, time_ids, lora_down_flat,
+                                    lora_up_flat, multipliers[0], save_for_backward, eps_out);
+  SMI_CHECK(e->n_conv_sites == 0 && e->dora_sites.empty(),
+            "per-sample multipliers are implemented for Linear LoRA sites (attention projections, time_emb_proj, "
+            "conv_shortcut); this network has conv or DoRA sites -- run the samples in separate passes");
+  float sig[smi_engine::MAXS];
+  for (int i = 0; i < n_adapted; ++i) sig[i] = multipliers[i] / mref;
+  // (tiny, from pageable host memory: the copy is staged before this returns, ordered on the engine's stream)
+  SMI_HIP(hipMemcpyAsync(e->samp_mult_dev, sig, n_adapted * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  if (save_for_backward)
+    SMI_HIP(hipMemcpyAsync(e->samp_mult_dev + smi_engine::MAXS, sig, n_adapted * sizeof(float), hipMemcpyHostToDevice,
+                           e->stream));
+  e->samp_on = true;
+  const int rc = smi_unet_forward_batched(e, n, n_adapted, sample, timestep, ctx, text_embeds, time_ids, lora_down_flat,
+                                          lora_up_flat, mref, save_for_backward, eps_out);
+  e->samp_on = false;
+  return rc;
 }
 
 int smi_unet_forward(smi_engine* e, int n, const float* sample, float timestep, const void* ctx,

@@ -189,9 +189,10 @@ struct HostLoraPrepSite {
   int64_t dst_gw;
 };
 // out[M, R] (fp32, row stride ldo) = X[M, K] * S[R, K]^T for R = 16 / 32 (LoRA shadow products), K % 128 == 0
+int launch_row_scale_f32(float* x, int ld, int M, int N, const float* row_mul, int rows_per_mul, hipStream_t stream);
 bool lora_skinny_supported(const void* X, int64_t ldx, const void* S, const float* out, int ldo, int M, int R, int K);
 int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, float* out, int ldo, int M, int R, int K,
-                       hipStream_t stream);
+                       hipStream_t stream, const float* row_mul = nullptr, int rows_per_mul = 1);
 // ---- DoRA (T/dora.py:124-162): dW = (W + up down) * (g / ||W + up down||_col) - W per adapted Linear (fused segments share W)
 struct DoraSite {
   const void* W;                       // frozen [nseg * cs, K], 16-bit

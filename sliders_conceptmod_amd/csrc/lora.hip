@@ -310,7 +310,8 @@ int launch_lora_prep(int dtype, const void* sites_dev, int n_sites, const float*
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int NF, int STEPS>  // NF = R / 16 column fragments, STEPS = 32-deep K-steps per wave and chunk
 __global__ __launch_bounds__(256) void lora_skinny_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ S,
-                                                          float* __restrict__ out, int ldo, int M, int K) {
+                                                          float* __restrict__ out, int ldo, int M, int K,
+                                                          const float* __restrict__ row_mul, int rows_per_mul) {
   __shared__ f32x4 red[3][NF][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -360,9 +361,34 @@ __global__ __launch_bounds__(256) void lora_skinny_kernel(const T* __restrict__ 
         v[2] += o[2];
         v[3] += o[3];
       }
+      if (row_mul) {  // per-sample adaptor multipliers (image sliders: +s / -s in one pass): out row *= m[sample] / m_ref
+        const float rm = row_mul[(m0 + fr) / rows_per_mul];
+        v[0] *= rm;
+        v[1] *= rm;
+        v[2] *= rm;
+        v[3] *= rm;
+      }
       *reinterpret_cast<f32x4*>(out + (int64_t)(m0 + fr) * ldo + f * 16 + fq * 4) = v;
     }
   }
+}
+
+// out[m, 0..N) *= row_mul[m / rows_per_mul]: the per-sample multipliers for shapes the skinny kernel does not take
+__global__ void row_scale_f32_kernel(float* __restrict__ x, int ld, int M, int N, const float* __restrict__ row_mul,
+                                     int rows_per_mul) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+    x[(int64_t)m * ld + n] *= row_mul[m / rows_per_mul];
+  }
+}
+int launch_row_scale_f32(float* x, int ld, int M, int N, const float* row_mul, int rows_per_mul, hipStream_t stream) {
+  SMI_CHECK(x && row_mul && rows_per_mul > 0 && M > 0 && N > 0, "row_scale: bad arguments");
+  const int64_t total = (int64_t)M * N;
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(row_scale_f32_kernel, dim3(grid), dim3(256), 0, stream, x, ld, M, N, row_mul, rows_per_mul);
+  SMI_HIP(hipGetLastError());
+  return 0;
 }
 
 bool lora_skinny_supported(const void* X, int64_t ldx, const void* S, const float* out, int ldo, int M, int R, int K) {
@@ -372,12 +398,13 @@ bool lora_skinny_supported(const void* X, int64_t ldx, const void* S, const floa
 }
 
 int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, float* out, int ldo, int M, int R, int K,
-                       hipStream_t stream) {
+                       hipStream_t stream, const float* row_mul, int rows_per_mul) {
+  SMI_CHECK(!row_mul || rows_per_mul > 0, "lora_skinny: rows_per_mul must be positive");
   SMI_CHECK(lora_skinny_supported(X, ldx, S, out, ldo, M, R, K), "lora_skinny: unsupported layout (R=%d K=%d)", R, K);
   const int grid = cdiv(M, 16);
 #define GO(TT_, NF_)                                                                                          \
   hipLaunchKernelGGL((lora_skinny_kernel<TT_, NF_, 8>), dim3(grid), dim3(256), 0, stream, (const TT_*)X, ldx, \
-                     (const TT_*)S, out, ldo, M, K)
+                     (const TT_*)S, out, ldo, M, K, row_mul, rows_per_mul)
   if (dtype == DT_F16) {
     if (R == 16) GO(f16, 1); else GO(f16, 2);
   } else {

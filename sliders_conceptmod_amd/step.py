@@ -257,15 +257,19 @@ class ImageSliderStep:
         slider -s : eps = predict_noise(_xl)(low_noised,  neutral prompt)  -> MSE(eps, low_noise)  -> backward
         (gradients accumulate in the flat fp32 buffer) -> all-reduce -> AdamW
 
-    Same arithmetic and order as `train_lora_scale_xl.image_slider_step` + torch.optim.AdamW (tested against it); the
-    two sides cannot share one UNet pass because their adaptor multipliers differ (+s / -s)."""
+    Same arithmetic and order as `train_lora_scale_xl.image_slider_step` + torch.optim.AdamW (tested against it).  The two
+    sides differ in their adaptor multiplier (+s / -s); with Linear-only adaptors they still share ONE UNet pass and one
+    backward through per-sample multipliers (`smi_unet_forward_multi`: twice the GEMM rows, half the launches); conv
+    (c3lier) or DoRA adaptors fall back to one pass per side."""
 
     def __init__(self, unet, network, scheduler, *, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, max_grad_norm: float = 0.0, process_group=None):
+                 weight_decay: float = 1e-2, max_grad_norm: float = 0.0, process_group=None, one_pass: bool = True):
         self.unet, self.network, self.scheduler = unet, network, scheduler
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.pg = process_group
+        self.one_pass = one_pass  # both sides in one UNet pass where the adaptor set allows it (see _one_pass_ok)
+        self._one_pass_cached = None
         flat = network.flat
         self.grad = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat)
@@ -311,13 +315,53 @@ class ImageSliderStep:
         d_eps = torch.cat([dpred * (1.0 - guidance_scale), dpred * guidance_scale])  # d(u + g (t - u))
         engine.backward(d_eps.contiguous(), self.grad[:n_down], self.grad[n_down:])  # accumulates
 
+    def _one_pass_ok(self) -> bool:
+        """Both sides can share ONE UNet pass (per-sample adaptor multipliers +s / -s, smi_unet_forward_multi) when every
+        adaptor sits on a Linear layer: plain LoRA, no conv (c3lier) sites."""
+        if self._one_pass_cached is None:
+            net = self.network
+            self._one_pass_cached = type(net).__name__ == "LoRANetwork" and all(
+                not getattr(l, "is_conv", False) and len(l.lora_down._shape) == 2 for l in net.unet_loras)
+        return self._one_pass_cached
+
+    def _both_sides(self, scale, noised_high, noised_low, noise_high, noise_low, timestep, cond_pos, cond_neu,
+                    guidance_scale):
+        net = self.network
+        B = noised_high.shape[0]
+        x = torch.cat([noised_high.float()] * 2 + [noised_low.float()] * 2)       # [high CFG pair | low CFG pair]
+        x = self.scheduler.scale_model_input(x, timestep).contiguous()
+        n, _, h, w = x.shape
+        c = {k: torch.cat([cond_pos[k], cond_neu[k]]).contiguous() for k in cond_pos}
+        engine = self.unet._ensure_engine(n, h, w, c["ctx"].shape[1])
+        net.set_lora_slider(scale=1)
+        net.__enter__()
+        flat, n_down, mult = net.engine_params()
+        net.__exit__(None, None, None)
+        mults = [mult * scale] * (2 * B) + [-mult * scale] * (2 * B)
+        eps = engine.forward(x, float(timestep), c["ctx"], c.get("text_embeds"), c.get("time_ids"), flat[:n_down],
+                             flat[n_down:], mults, True)
+        d_parts = []
+        for idx, (e, noise) in enumerate(((eps[:2 * B], noise_high), (eps[2 * B:], noise_low))):
+            pred = torch.empty((B,) + tuple(e.shape[1:]), dtype=torch.float32, device=e.device)
+            _native.check(self._lib.smi_cfg_combine(_native.ptr(e.contiguous()), _native.ptr(pred), pred.numel(),
+                                                    float(guidance_scale), _native.stream_ptr()), "smi_cfg_combine")
+            diff = pred - noise.float()
+            self.losses[idx] = (diff * diff).mean()
+            dpred = diff * (2.0 / diff.numel())
+            d_parts += [dpred * (1.0 - guidance_scale), dpred * guidance_scale]
+        engine.backward(torch.cat(d_parts).contiguous(), self.grad[:n_down], self.grad[n_down:])
+
     def train_step(self, noised_low, noised_high, noise_low, noise_high, timestep, cond_pos: dict, cond_neu: dict,
                    scale: float, guidance_scale: float = 1.0, lr: Optional[float] = None) -> torch.Tensor:
         """One optimisation step; returns the two side losses (high, low) as a device tensor (no host sync)."""
         net = self.network
         self.grad.zero_()
-        self._side(0, +scale, noised_high, noise_high, timestep, cond_pos, guidance_scale)
-        self._side(1, -scale, noised_low, noise_low, timestep, cond_neu, guidance_scale)
+        if self.one_pass and self._one_pass_ok():
+            self._both_sides(scale, noised_high, noised_low, noise_high, noise_low, timestep, cond_pos, cond_neu,
+                             guidance_scale)
+        else:
+            self._side(0, +scale, noised_high, noise_high, timestep, cond_pos, guidance_scale)
+            self._side(1, -scale, noised_low, noise_low, timestep, cond_neu, guidance_scale)
         net.set_lora_slider(scale=1)
         parallel.allreduce_mean_(self.grad, self.pg)
         self.step_count += 1

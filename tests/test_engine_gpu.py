@@ -423,3 +423,46 @@ def test_dora_forward_and_gradients_match_oracle(model, method):
     pnet.__exit__(None, None, None)
     with torch.no_grad():
         assert rel(pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample, off) < LOOSE[dtype]
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+def test_per_sample_multipliers_equal_separate_passes(model):
+    """smi_unet_forward_multi: the image-slider step's two sides (adaptor at +s on one CFG pair, -s on the other) as ONE UNet
+    pass with one multiplier per adapted sample must give the eps of two separate passes bit for bit (per-sample arithmetic
+    does not depend on batch composition; the multiplier only rescales the rows of xa = x down^T), and -- after one
+    backward over all four samples -- the LoRA gradient of the two separate backward passes accumulated (fp32 order).
+    A network with conv adaptors must refuse unequal multipliers."""
+    from sliders_conceptmod_amd import _native
+    dtype = torch.float16
+    ocfg, ou, onet, pu, pnet = build_pair(model, dtype)
+    x, ctx, add = inputs(ocfg, 4, 16)
+    cadd = cuda_add(add)
+    te, ti = (cadd["text_embeds"].half().contiguous(), cadd["time_ids"].float().contiguous()) if cadd else (None, None)
+    xc, cc = x.cuda().float().contiguous(), ctx.cuda().half().contiguous()
+    flat, n_down, _ = pnet.engine_params()
+    down, up = flat[:n_down], flat[n_down:]
+    eng = pu._ensure_engine(4, 16, 16, 77)
+    gy = (torch.randn(4, 4, 16, 16, generator=torch.Generator().manual_seed(9)) * 1e-4).cuda()
+    s = 1.5
+    # one pass, per-sample multipliers
+    eps = eng.forward(xc, 499.0, cc, te, ti, down, up, [s, s, -s, -s], True)
+    g1 = torch.zeros_like(flat)
+    eng.backward(gy.contiguous(), g1[:n_down], g1[n_down:])
+    # two passes
+    g2 = torch.zeros_like(flat)
+    parts = []
+    for sl, m in ((slice(0, 2), s), (slice(2, 4), -s)):
+        e = eng.forward(xc[sl].contiguous(), 499.0, cc[sl].contiguous(), None if te is None else te[sl].contiguous(),
+                        None if ti is None else ti[sl].contiguous(), down, up, m, True)
+        eng.backward(gy[sl].contiguous(), g2[:n_down], g2[n_down:])
+        parts.append(e)
+    assert torch.equal(eps, torch.cat(parts)), "per-sample multipliers changed a sample's forward arithmetic"
+    relg = float((g1 - g2).norm() / g2.norm())
+    assert relg < 1e-5, relg
+    assert rel(eps[:2], eps[2:]) > 1e-4  # (+s and -s really differ)
+    # conv adaptors: refused
+    _, _, _, pu2, pnet2 = build_pair(model, dtype, c3lier=True)
+    flat2, nd2, _ = pnet2.engine_params()
+    eng2 = pu2._ensure_engine(4, 16, 16, 77)
+    with pytest.raises(_native.SmiError, match="per-sample multipliers"):
+        eng2.forward(xc, 499.0, cc, te, ti, flat2[:nd2], flat2[nd2:], [s, s, -s, -s], False)
