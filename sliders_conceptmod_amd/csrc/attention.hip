@@ -164,10 +164,18 @@ __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r 
 // EX: head_dim == DP (SD-XL: 64).  The number of 16-wide k-steps is then a compile-time constant -- with the run-time
 // `s < nsd` test hipcc wraps every (ds_read, MFMA) pair of the QK^T product in its own branch and waits lgkmcnt(0) after
 // each read: eight exposed LDS round trips per key tile and wave instead of eight reads in flight.
-template <typename T, int DP, bool EX>
+// PRE (with EX): the query fragments are pre-multiplied by scale * log2(e) when they are loaded (once per workgroup; one
+// more 16-bit rounding of Q, of the size of the rounding Q already carries) and the running reference enters the score
+// product as its INITIAL ACCUMULATOR (-m_run in all sixteen registers: the query is on the lane, so it is a lane
+// constant, and it changes only when the lazy rescale fires).  The score tile then leaves its MFMA chain as
+// log2-domain exponents relative to the reference: p = exp2(acc), no multiply, no subtraction -- 32 of the ~150 VALU
+// instructions per key tile of a loop whose busiest resource is the SIMD's vector issue port (rocprofv3: VALU 60 %,
+// MFMA 47 % busy).
+template <typename T, int DP, bool EX, bool PRE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
+  static_assert(!PRE || (EX && NS <= 4), "PRE is the head_dim == tile depth form");
   // two LDS stages: tile t + 1 is written while tile t is being read, so ONE barrier per key tile orders both the
   // "everyone is done with stage s" and the "stage s ^ 1 is complete" edges (it was two barriers on one stage)
   __shared__ __attribute__((aligned(16))) T Ks2[2][TK * S::LDN];
@@ -194,15 +202,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     t.u = buf_load16(rQ, ok ? (uint32_t)(((int64_t)q_idx * p.ldq + col0 + d) * 2) : OOB);
     qf[s] = t.v;
   }
+  const float sl = p.scale * LOG2E;
+  if constexpr (PRE) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = from_f<T>(to_f(qf[s][j]) * sl);
+  }
 
   f32x16 o[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -INFINITY;
+  float m_run = PRE ? 0.f : -INFINITY;  // PRE: in the log2 domain of the pre-scaled scores, fixed by the first tile
+  f32x16 minit;                         // PRE: -m_run in every register, the initial accumulator of the score chains
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
   f32x4 l4 = {0.f, 0.f, 0.f, 0.f};  // running row sum (all four registers equal), see Sum4
-  const float sl = p.scale * LOG2E;
 
   const int ntiles = (p.Nk + TK - 1) / TK;
   // K/V tiles are fetched one tile ahead into registers: the global-load latency hides under the MFMAs / softmax
@@ -240,10 +257,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int s = 0; s < NS; ++s) kfr[sub][s] = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
+        if constexpr (PRE) {
+          st[sub] = TT<T>::mfma32(kfr[sub][0], qf[0], minit);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+          for (int s = 1; s < NS; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
+        } else {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
+          for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
+        }
       }
     } else {
 #pragma unroll
@@ -279,22 +302,47 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     // exponent domain; until then probabilities are formed against the stale reference (p <= 256: exact in fp32,
     // representable in fp16 / bf16) and O, l stay un-rescaled.  o / l is unchanged mathematically; it saves the
     // 16 NB accumulator multiplies and an exp per tile on all but the first tile or two -- the loop is VALU-bound.
-    const bool need = (mloc - m_run) * sl > 8.f;  // both halves of a query agree (mloc is already combined)
-    if (__builtin_amdgcn_ballot_w64(need)) {
-      const float m_new = need ? mloc : m_run;
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl);  // 1 for lanes that keep their reference
-      m_run = m_new;
-      l4 *= alpha;
+    if constexpr (PRE) {
+      // mloc is already relative to the reference; the first tile always fixes it (whatever the size of its scores)
+      const bool need = kt == 0 || mloc > 8.f;
+      if (__builtin_amdgcn_ballot_w64(need)) {
+        const float d = need ? mloc : 0.f;
+        const float alpha = __builtin_amdgcn_exp2f(-d);  // 1 for lanes that keep their reference
+        m_run += d;
+        l4 *= alpha;
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) minit[r] -= d;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[sub][r] -= d;  // this tile's exponents were formed against the old reference
+      }
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[sub][r] = __builtin_amdgcn_exp2f(st[sub][r]);
+    } else {
+      const bool need = (mloc - m_run) * sl > 8.f;  // both halves of a query agree (mloc is already combined)
+      if (__builtin_amdgcn_ballot_w64(need)) {
+        const float m_new = need ? mloc : m_run;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl);  // 1 for lanes that keep their reference
+        m_run = m_new;
+        l4 *= alpha;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+      const float mb = m_run * sl;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[sub][r] = __builtin_amdgcn_exp2f(st[sub][r] * sl - mb);
     }
-    const float mb = m_run * sl;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[sub][r] = __builtin_amdgcn_exp2f(st[sub][r] * sl - mb);
     // O^T[d, q] += V^T[d, keys] . P^T[keys, q]
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -328,7 +376,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           *reinterpret_cast<u32x2*>(orow + d) = t.u;
         }
       }
-    if (p.lse && h2 == 0) p.lse[((int64_t)b * p.H + head) * p.Nq + q_idx] = m_run * p.scale + __logf(l_tot);
+    if (p.lse && h2 == 0)
+      p.lse[((int64_t)b * p.H + head) * p.Nq + q_idx] =
+          (PRE ? m_run * 0.6931471805599453f : m_run * p.scale) + __logf(l_tot);
   }
 }
 
@@ -668,10 +718,18 @@ int check_attn(const AttnParams& p) {
 template <typename T, int DP>
 int fwd_t(const AttnParams& p, hipStream_t st) {
   dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
+  static const bool pre = []() { const char* e = getenv("SMI_ATTN_PRESCALE"); return !(e && e[0] == '0'); }();
+  if constexpr (DP <= 64) {
+    if (p.D == DP && pre) {
+      hipLaunchKernelGGL((attn_fwd_kernel<T, DP, true, true>), grid, dim3(256), 0, st, p);
+      SMI_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   if (p.D == DP)
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, true>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, true, false>), grid, dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, false, false>), grid, dim3(256), 0, st, p);
   SMI_HIP(hipGetLastError());
   return 0;
 }

@@ -344,12 +344,26 @@ struct smi_engine {
   do {                                     \
     if (!dry && !err) {                    \
       prof_begin(cat, flops, bytes);       \
+      if (trace_launches) trace_before(#call); \
       if ((call) != 0) {                   \
         err = true;                        \
       }                                    \
+      if (trace_launches) trace_after();   \
       prof_end();                          \
     }                                      \
   } while (0)
+  // SMI_TRACE_LAUNCH=1 (debugging a hang): names every launch on stderr and waits for it, so the last line printed is the
+  // launch that never came back
+  bool trace_launches = getenv("SMI_TRACE_LAUNCH") != nullptr;
+  void trace_before(const char* what) {
+    fprintf(stderr, "[smi launch] %.110s ...", what);
+    fflush(stderr);
+  }
+  void trace_after() {
+    const hipError_t e = hipStreamSynchronize(stream);
+    fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+    fflush(stderr);
+  }
 
   // ---- per-kernel-class timing with HIP events on the engine's stream (profiling mode only)
   bool prof_on = false;

@@ -22,9 +22,10 @@ KT=$(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1)
 python3 tools/trace_steps.py $KT $OUT/${TAG}_bench_under_rocprof_${CFG}.json $OUT/${TAG}_trace_steps_${CFG}.json
 gzip -c $KT > $OUT/${TAG}_kernel_trace_${CFG}.csv.gz
 echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmcf -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmcf.err
+# (SMI_TRACE_LAUNCH=1: the engine waits for every launch -- un-synchronised, a --pmc pass of this command hung once in round 3)
+SMI_TRACE_LAUNCH=1 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmcf -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmcf.err
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmcw -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmcw.err
+SMI_TRACE_LAUNCH=1 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmcw -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmcw.err
 echo "write done"
 python3 tools/pmc_traffic.py $OUT/${TAG}_pmcf $OUT/${TAG}_pmcw $OUT/${TAG}_pmc_traffic_${CFG}.json > $OUT/${TAG}_pmc_summary_${CFG}.txt
 rm -rf $OUT/${TAG}_pmcf $OUT/${TAG}_pmcw $OUT/${TAG}_trace

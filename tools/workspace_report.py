@@ -16,7 +16,7 @@ for name, cfg, res, B, rank in (("C1 SD-1.4 512^2 B=1", PU.sd1x_config(), 512, 1
         unet = PU.UNet2DConditionModel(cfg)
     net = L.LoRANetwork(unet, rank=rank, alpha=1.0, train_method="noxattn")
     cc = _native.make_config(cfg, torch.float16)
-    n, na = (2, 2) if B == 0 else (8 * B, 2 * B)
+    n, na = (4, 4) if B == 0 else (8 * B, 2 * B)  # image slider: both sides of one pair in one pass (2 CFG pairs)
     tot = _native.workspace_bytes(cc, net.engine_sites(), n, res // 8, res // 8, 77, na)
     arena = _native.arena_bytes(cc, net.engine_sites(), n, res // 8, res // 8, 77, na)
     print(f"{name:40s} UNet batch {n:3d} ({na:2d} adapted): workspace {tot / 1e9:7.1f} GB = packed weights {(tot - arena) / 1e9:5.1f} GB "
