@@ -5,6 +5,8 @@ minute each on 8-16 threads; not collected by pytest):
                                                       (oracle with storage_dtype = fp16, exact fp32 autograd backward)
     python tests/parity_floor.py sites [sdxl|sd1x]   eps error of each of the oracle's rounding sites alone (ablation), and of
                                                       all of them with the transformer residual stream kept in fp32
+    python tests/parity_floor.py blocks [sdxl|sd1x]  eps error of the rounding sites of ONE top-level block at a time, and
+                                                      with the last up block / the top level kept exact
 
 Real SD-1.x / SD-XL widths (synthetic weights) at 32 x 32 latents, rank 4, noxattn -- the configuration of
 tests/test_fullsize_gpu.py, so the numbers sit next to the engine's measured distances."""
@@ -88,8 +90,54 @@ def sites(model):
     print(f"  root-sum-square of the single-site errors {tot ** 0.5:.3e}")
 
 
+def blocks(model):
+    """eps error with fp16 storage rounding in ONE top-level block at a time (down_blocks.i / mid_block / up_blocks.i; "top" =
+    conv_in, the time-embedding MLPs, conv_norm_out / conv_out), and with the last blocks kept exact -- what fp32 storage of
+    "the last few tensors" could buy."""
+    ocfg, ou, x, ctx, add, _ = setup(model, 1)
+    cur = ["top"]
+
+    def wrap(name, m):
+        f = m.forward
+
+        def g(*a, **k):
+            prev, cur[0] = cur[0], name
+            try:
+                return f(*a, **k)
+            finally:
+                cur[0] = prev
+        m.forward = g
+
+    for i, b in enumerate(ou.down_blocks):
+        wrap(f"down{i}", b)
+    wrap("mid", ou.mid_block)
+    for i, b in enumerate(ou.up_blocks):
+        wrap(f"up{i}", b)
+    counts = collections.Counter()
+    only = [None]
+
+    def tagged_q(t):
+        counts[cur[0]] += 1
+        return t.to(torch.float16).to(t.dtype) if only[0] is None or only[0](cur[0]) else t
+
+    OU.q = tagged_q
+
+    def run(sel):
+        only[0] = sel
+        with torch.no_grad():
+            return ou(x, 499.0, ctx, add).sample
+
+    ref = run(lambda b: False)
+    print(f"{model}: all sites {float((run(None) - ref).norm() / ref.norm()):.3e}")
+    for b in sorted(counts):
+        print(f"  only {b:6s} x{counts[b]:4d}  {float((run(lambda bb, b=b: bb == b) - ref).norm() / ref.norm()):.3e}", flush=True)
+    last = sorted(counts)[-1]
+    for excl in (["top"], [last], ["top", last]):
+        print(f"  all but {excl}: {float((run(lambda bb: bb not in excl) - ref).norm() / ref.norm()):.3e}", flush=True)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     what = sys.argv[1] if len(sys.argv) > 1 else "grad"
     model = sys.argv[2] if len(sys.argv) > 2 else "sdxl"
-    {"grad": grad_floor, "sites": sites}[what](model)
+    {"grad": grad_floor, "sites": sites, "blocks": blocks}[what](model)
