@@ -257,24 +257,6 @@ def test_attention_forward_backward(lib, dt, B, H, Nq, Nk, D):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_attention_forward_16x16x32_variant(lib, dt, monkeypatch):
-    """The head_dim-64 forward on v_mfma_f32_16x16x32 (SMI_ATTN_MFMA16=1; measured no faster, kept selectable): same parity
-    bar as the default kernel, incl. a ragged key count, a spiked key (rescale branch) and the lse the backward consumes."""
-    monkeypatch.setenv("SMI_ATTN_MFMA16", "1")
-    for (B, H, Nq, Nk) in ((2, 3, 320, 77), (2, 4, 256, 1024), (1, 2, 200, 300)):
-        D = 64
-        q, k, v = rnd(B, Nq, H, D, dt=dt, seed=1), rnd(B, Nk, H, D, dt=dt, seed=2), rnd(B, Nk, H, D, dt=dt, seed=3)
-        if Nk > 250:
-            k[0, 230, 0] = (q[0, 5, 0].float() * 6).to(dt)
-        o = torch.empty_like(q)
-        lse = torch.empty(B, H, Nq, device="cuda")
-        chk(lib, lib.smi_op_attention_fwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), B, H, Nq, Nk, D, D ** -0.5, None))
-        oref, lref = attn_ref(q.float(), k.float(), v.float(), D ** -0.5)
-        close(o, oref, dt, what=f"attn16 O {Nq}x{Nk}")
-        torch.testing.assert_close(lse, lref, rtol=1e-4, atol=2e-3)
-
-
-@pytest.mark.parametrize("dt", DT)
 def test_attention_rescale_branch_with_spiked_key(lib, dt):
     """Forces the online-softmax running max to jump in a LATE key tile (guide rule 26)."""
     B, H, N, D = 1, 1, 256, 64
@@ -283,8 +265,9 @@ def test_attention_rescale_branch_with_spiked_key(lib, dt):
     o = torch.empty_like(q)
     lse = torch.empty(B, H, N, device="cuda")
     chk(lib, lib.smi_op_attention_fwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), B, H, N, N, D, D ** -0.5, None))
-    oref, _ = attn_ref(q.float(), k.float(), v.float(), D ** -0.5)
+    oref, lref = attn_ref(q.float(), k.float(), v.float(), D ** -0.5)
     close(o, oref, dt, what="attn O (spiked)")
+    torch.testing.assert_close(lse, lref, rtol=1e-4, atol=2e-3)  # what the backward recomputes P against
 
 
 @pytest.mark.parametrize("dt", DT)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Final measurement set of round 3 (run through gpurun): profiles of the headline config + bench records of every BASELINE
+# The measurement set of a round (run through gpurun; usage: bash tools/measure_round.sh <tag>): profiles of the headline config + bench records of every BASELINE
 # configuration + counters.
 set -e -o pipefail
 cd "$(dirname "$0")/.."
