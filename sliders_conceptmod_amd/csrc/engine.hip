@@ -1069,7 +1069,12 @@ struct smi_engine {
         (void)j;
       };
       push(dy, L->out, xa, d_up ? d_up + L->off_up : nullptr, 1, r, L->out, r, L->nseg > 1 ? cs : 0);
-      if (rtot <= 32) {
+      // all segments of a fused projection in one job only while their rank rows fit the 8-accumulator class; beyond that
+      // one job per segment: x is read once per segment, but the reduction kernel keeps R x 8 fp32 accumulators per thread
+      // and its speed falls with R -- rank 8 on q|k|v (24 rows -> the 32-row class, 256 accumulators) took 7.5 ms per step
+      // (lora class 12.7 -> 5.9 ms split), rank 4 (12 rows -> the 16-row class) 5.1 -> 4.7 ms.  SMI_WGRAD_SEG_MAX overrides.
+      static const int seg_max = []() { const char* e = getenv("SMI_WGRAD_SEG_MAX"); return e ? atoi(e) : 8; }();
+      if (rtot <= seg_max) {
         push(PA(x), x->cols, dxa, d_down ? d_down + L->off_down : nullptr, L->in, 1, L->in, rtot, 0);
       } else {
         for (int sg = 0; sg < L->nseg; ++sg) {
