@@ -204,7 +204,7 @@ struct smi_engine {
   std::vector<WgradJob> wjobs;
   std::vector<WgradJob> wjobs_uploaded;  // what the device table holds (same addresses every step of a plan: no re-upload)
   WgradJob* wjobs_dev = nullptr;
-  static constexpr size_t SPLITK_WS_BYTES = (size_t)384 * 128 * 128 * sizeof(float);  // 25 MB
+  static constexpr size_t SPLITK_WS_BYTES = (size_t)512 * 128 * 128 * sizeof(float);  // 33.5 MB
   void* splitk_ws = nullptr;
   // per-sample adaptor multipliers (smi_unet_forward_multi): sigma_i = m_i / m_ref per ADAPTED sample, applied to the rows
   // of xa = x down^T (forward) and dxa = dy up (backward) -- every other use of the multiplier stays the scalar m_ref.
@@ -1397,7 +1397,9 @@ struct smi_engine {
           while ((1 << (2 * (k + 1))) <= Hout * Wout) ++k;
           rowvec->gmul = exp2f((float)-k);
           rowvec->g = alloc_t(MA(rowvec), rowvec->cols);
-          RUNP(SMI_PROF_ELEM, 0.0, 0.0, launch_colsum(dtype, dy, rowvec->g, nb_ad, Hout * Wout, cp->Cout, rowvec->gmul, stream));
+          float* cs_scratch = alloc_f32(colsum_scratch_floats(nb_ad, cp->Cout));
+          RUNP(SMI_PROF_ELEM, 0.0, 0.0,
+               launch_colsum(dtype, dy, rowvec->g, cs_scratch, nb_ad, Hout * Wout, cp->Cout, rowvec->gmul, stream));
         }
         float* dxa = nullptr;
         if (lon) {

@@ -144,7 +144,9 @@ int launch_softmax_rows(int dtype, const float* S, void* P, int rows, int cols, 
 int launch_chan_mix(int dtype, const float* x, const void* W, const void* b, float* y, int64_t M, int C,
                     hipStream_t stream);
 // out[n][c] = mul * sum over the HW rows of sample n of x[n][hw][c]   (deterministic)
-int launch_colsum(int dtype, const void* x, void* out, int Nb, int HW, int C, float mul, hipStream_t stream);
+size_t colsum_scratch_floats(int Nb, int C);  // fp32 scratch launch_colsum needs
+int launch_colsum(int dtype, const void* x, void* out, float* scratch, int Nb, int HW, int C, float mul,
+                  hipStream_t stream);
 // dst[M][cpad] (T) = src[M][0..cols) (fp32, row stride lds) * mul, zero padded
 int launch_f32_to_padded(int dtype, const float* src, int lds, int cols, void* dst, int cpad, int64_t M, float mul,
                          hipStream_t stream);

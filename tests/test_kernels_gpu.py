@@ -95,7 +95,7 @@ def test_splitk_rule_gemm_and_conv(lib, dt):
     the time-embedding MLPs): fp32 slabs per K-slice + one finish kernel with the full epilogue.  Against fp32 torch on the
     same rounded inputs, with and without the scratch (the unsplit kernels), bit-reproducible run to run, every epilogue
     term, dense and conv (plain, stride 2, transposed gradient)."""
-    ws = torch.empty(384 * 128 * 128, device="cuda", dtype=torch.float32)
+    ws = torch.empty(512 * 128 * 128, device="cuda", dtype=torch.float32)
     try:
         for (M, N, K, r) in ((128, 1280, 11520, 4), (512, 1280, 10240, 0), (16, 1280, 1280, 0), (2048, 640, 5120, 8),
                              (136, 324, 2048, 0)):

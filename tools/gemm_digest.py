@@ -26,7 +26,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     rn = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc)
     out = {}
-    ws = torch.empty(384 * 128 * 128, device="cuda", dtype=torch.float32)  # split-K scratch, as the engine lends it
+    ws = torch.empty(512 * 128 * 128, device="cuda", dtype=torch.float32)  # split-K scratch, as the engine lends it
     _native.check(lib.smi_op_gemm_scratch(P(ws), ws.numel() * 4), "scratch")
     for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
         tag = "f16" if code == 0 else "bf16"
