@@ -641,7 +641,8 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
       if (p.conv) {
         SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout, "conv: inconsistent geometry");
       }
-      return launch_gemm2(p, 11, stream);
+      static const int deep_variant = []() { const char* e = getenv("SMI_GEMM_DEEP_VARIANT"); return e ? atoi(e) : 11; }();
+      return launch_gemm2(p, deep_variant, stream);  // (11 = eight-wave 128 x 160 deep loop; others for A/B experiments)
     }
   }
   if (gemm_mode() == 0 && tune_enabled() && gemm2_supported(p) && (int64_t)p.M * p.N >= (1 << 17)) {
