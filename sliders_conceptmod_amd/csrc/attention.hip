@@ -162,7 +162,8 @@ __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r 
 // =============================================================================================================
 // forward
 // =============================================================================================================
-// EX: head_dim == DP (SD-XL: 64).  The number of 16-wide k-steps is then a compile-time constant -- with the run-time
+// NSD > 0 ("EX"): the number of 16-wide k-steps of the head dimension is a compile-time constant -- head_dim == DP (SD-XL:
+// 64 -> 4) or one of the SD-1.x widths inside a wider tile (40 -> 3 of the 64-wide tile, 80 -> 5 of the 96-wide one) -- with the run-time
 // `s < nsd` test hipcc wraps every (ds_read, MFMA) pair of the QK^T product in its own branch and waits lgkmcnt(0) after
 // each read: eight exposed LDS round trips per key tile and wave instead of eight reads in flight.
 // PRE (with EX): the query fragments are pre-multiplied by scale * log2(e) when they are loaded (once per workgroup; one
@@ -172,11 +173,12 @@ __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r 
 // log2-domain exponents relative to the reference: p = exp2(acc), no multiply, no subtraction -- 32 of the ~150 VALU
 // instructions per key tile of a loop whose busiest resource is the SIMD's vector issue port (rocprofv3: VALU 60 %,
 // MFMA 47 % busy).
-template <typename T, int DP, bool EX, bool PRE>
+template <typename T, int DP, int NSD, bool PRE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
-  static_assert(!PRE || (EX && NS <= 4), "PRE is the head_dim == tile depth form");
+  constexpr bool EX = NSD > 0;  // the number of 16-wide k-steps is the compile-time NSD (0: run-time, from p.D)
+  static_assert(!PRE || (NSD == NS && NS <= 4), "PRE is the head_dim == tile depth form");
   // two LDS stages: tile t + 1 is written while tile t is being read, so ONE barrier per key tile orders both the
   // "everyone is done with stage s" and the "stage s ^ 1 is complete" edges (it was two barriers on one stage)
   __shared__ __attribute__((aligned(16))) T Ks2[2][TK * S::LDN];
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   xcd_block(bx, head, b);
   const int q_idx = bx * 128 + wave * 32 + ql;
   const int col0 = head * p.D;
-  const int nsd = EX ? DP / 16 : (p.D + 15) / 16;
+  const int nsd = NSD > 0 ? NSD : (p.D + 15) / 16;
 
   const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
   const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
@@ -248,25 +250,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
 
     f32x16 st[2];
-    if constexpr (EX && NS <= 4) {
-      // all K fragments of the tile in flight before the first MFMA (2 * NS * 4 registers): hipcc otherwise recycles
+    if constexpr (EX && NSD <= 4) {
+      // all K fragments of the tile in flight before the first MFMA (2 * NSD * 4 registers): hipcc otherwise recycles
       // two fragment registers and waits for every read right in front of the MFMA that consumes it
-      typename TT<T>::v8 kfr[2][NS];
+      typename TT<T>::v8 kfr[2][NSD > 0 ? NSD : 1];
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) kfr[sub][s] = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
+        for (int s = 0; s < NSD; ++s) kfr[sub][s] = ld_frag_nat<T>(Ks, S::LDN, sub * 32 + ql, 16 * s + 8 * h2);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         if constexpr (PRE) {
           st[sub] = TT<T>::mfma32(kfr[sub][0], qf[0], minit);
 #pragma unroll
-          for (int s = 1; s < NS; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
+          for (int s = 1; s < NSD; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
 #pragma unroll
-          for (int s = 0; s < NS; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
+          for (int s = 0; s < NSD; ++s) st[sub] = TT<T>::mfma32(kfr[sub][s], qf[s], st[sub]);
         }
       }
     } else {
@@ -414,7 +416,7 @@ __global__ void attn_delta_kernel(AttnParams p) {
 // =============================================================================================================
 // REMAT: re-broadcast the two row constants in front of every chain (32 v_mov per 32-key sub-tile) instead of keeping
 // two 16-register copies alive across the loop (0 VALU, +32 registers: 2 waves per SIMD instead of 3)
-template <typename T, int DP, bool EX, bool REMAT>
+template <typename T, int DP, int NSD, bool REMAT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   xcd_block(bx, head, b);
   const int q_idx = bx * 128 + wave * 32 + ql;
   const int col0 = head * p.D;
-  const int nsd = EX ? DP / 16 : (p.D + 15) / 16;
+  const int nsd = NSD > 0 ? NSD : (p.D + 15) / 16;
 
   const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
   const auto rG = make_rsrc((const T*)p.dO + (int64_t)b * p.Nq * p.lddo, (uint32_t)((int64_t)p.Nq * p.lddo * 2));
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 //   dV^T[d,key] += dO^T[d,q] P[q,key] ;  dK^T[d,key] += Q^T[d,q] dS[q,key]
 // WHICH: 1 = dK only, 2 = dV only, 3 = both (register budget: both only fits for DP <= 96)
 // =============================================================================================================
-template <typename T, int DP, int WHICH, bool EX>
+template <typename T, int DP, int WHICH, int NSD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   xcd_block(bx, head, b);
   const int k_idx = bx * 128 + wave * 32 + kl;
   const int col0 = head * p.D;
-  const int nsd = EX ? DP / 16 : (p.D + 15) / 16;
+  const int nsd = NSD > 0 ? NSD : (p.D + 15) / 16;
 
   const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
   const auto rG = make_rsrc((const T*)p.dO + (int64_t)b * p.Nq * p.lddo, (uint32_t)((int64_t)p.Nq * p.lddo * 2));
@@ -716,9 +718,15 @@ int check_attn(const AttnParams& p) {
   return 0;
 }
 
+// compile-time k-step counts offered for a tile depth DP: the full depth, and the SD-1.x head widths that sit inside a
+// wider tile (40 -> 3 steps of DP = 64, 80 -> 5 steps of DP = 96); anything else takes the run-time form (0)
+template <int DP> constexpr int alt_steps() { return DP == 64 ? 3 : (DP == 96 ? 5 : 0); }
+
 template <typename T, int DP>
 int fwd_t(const AttnParams& p, hipStream_t st) {
   dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
+  constexpr int NS = DP / 16, ALT = alt_steps<DP>();
+  const int nsd = (p.D + 15) / 16;
   // OFF by default (opt in with SMI_ATTN_PRESCALE=1): +4..7 % on the forward, but the re-rounded Q costs accuracy on peaked
   // rows -- log-sum-exp 2.9e-3 off on the spiked-key test (bar 2e-3 + 1e-4 rel), worst saved-weight element of the
   // SD-XL trajectory test 2.2e-3 -> 5.1e-3 -- and parity is the first gate
@@ -727,21 +735,40 @@ int fwd_t(const AttnParams& p, hipStream_t st) {
   constexpr bool is_f16 = sizeof(T) == 2 && std::is_same<T, f16>::value;
   if constexpr (DP <= 64 && is_f16) {
     if (p.D == DP && pre) {
-      hipLaunchKernelGGL((attn_fwd_kernel<T, DP, true, true>), grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, DP, NS, true>), grid, dim3(256), 0, st, p);
       SMI_HIP(hipGetLastError());
       return 0;
     }
   }
-  if (p.D == DP)
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, true, false>), grid, dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, false, false>), grid, dim3(256), 0, st, p);
+  if (nsd == NS) {
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, NS, false>), grid, dim3(256), 0, st, p);
+  } else if (ALT > 0 && nsd == ALT) {
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, (ALT > 0 ? ALT : NS), false>), grid, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DP, 0, false>), grid, dim3(256), 0, st, p);
+  }
   SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int DP, int WHICH, int NSD>
+int dkv_launch(const AttnParams& p, dim3 grid, size_t sm, hipStream_t st) {
+  static bool attr_set = false;  // (per instantiation)
+  if (!attr_set && sm > 65536) {
+    SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, WHICH, NSD>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, WHICH, NSD>), grid, dim3(256), sm, st, p);
   return 0;
 }
 
 template <typename T, int DP>
 int bwd_t(const AttnParams& p, hipStream_t st) {
+  constexpr int NS = DP / 16, ALT = alt_steps<DP>();
+  constexpr int ALTC = ALT > 0 ? ALT : NS;
+  const int nsd = (p.D + 15) / 16;
+  const int form = nsd == NS ? 1 : (ALT > 0 && nsd == ALT ? 2 : 0);  // 1: full depth, 2: the alternative, 0: run-time
   if (!p.dQ) {  // dK / dV only: nobody else forms delta
     const int64_t total = (int64_t)p.B * p.H * p.Nq;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -750,50 +777,28 @@ int bwd_t(const AttnParams& p, hipStream_t st) {
   if (p.dQ) {
     dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
     static const bool remat = []() { const char* e = getenv("SMI_ATTN_DQ_REMAT"); return e && e[0] == '1'; }();
-    if (p.D == DP && remat)
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, true, true>), grid, dim3(256), 0, st, p);
-    else if (p.D == DP)
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, true, false>), grid, dim3(256), 0, st, p);
+    if (form == 1 && remat)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NS, true>), grid, dim3(256), 0, st, p);
+    else if (form == 1)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NS, false>), grid, dim3(256), 0, st, p);
+    else if (form == 2)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, ALTC, false>), grid, dim3(256), 0, st, p);
     else
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, false, true>), grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, 0, true>), grid, dim3(256), 0, st, p);
   }
   if (p.dK || p.dV) {
     SMI_CHECK(p.dK && p.dV, "attention bwd: dK and dV must both be given");
     dim3 grid(cdiv(p.Nk, 128), p.H, p.B);
     const size_t sm = dkv_smem<T, DP>();
-    const bool ex = p.D == DP;
     if (DP <= 96) {
-      static bool attr_set = false;
-      if (!attr_set && sm > 65536) {
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 3, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 3, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        attr_set = true;
-      }
-      if (ex)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 3, true>), grid, dim3(256), sm, st, p);
-      else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 3, false>), grid, dim3(256), sm, st, p);
+      if (form == 1) { if (dkv_launch<T, DP, 3, NS>(p, grid, sm, st)) return -2; }
+      else if (form == 2) { if (dkv_launch<T, DP, 3, ALTC>(p, grid, sm, st)) return -2; }
+      else { if (dkv_launch<T, DP, 3, 0>(p, grid, sm, st)) return -2; }
     } else {
-      static bool attr_set = false;
-      if (!attr_set) {
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 1, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 2, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 1, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, 2, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        attr_set = true;
-      }
-      if (ex) {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 1, true>), grid, dim3(256), sm, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 2, true>), grid, dim3(256), sm, st, p);
+      if (form == 1) {
+        if (dkv_launch<T, DP, 1, NS>(p, grid, sm, st) || dkv_launch<T, DP, 2, NS>(p, grid, sm, st)) return -2;
       } else {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 1, false>), grid, dim3(256), sm, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, 2, false>), grid, dim3(256), sm, st, p);
+        if (dkv_launch<T, DP, 1, 0>(p, grid, sm, st) || dkv_launch<T, DP, 2, 0>(p, grid, sm, st)) return -2;
       }
     }
   }
