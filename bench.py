@@ -555,6 +555,13 @@ def main():
     pre_step.preroll(denoised, cond, n_pre, 3.0)
     torch.cuda.synchronize()
     preroll_ms = (time.perf_counter() - t0) * 1e3
+    if os.environ.get("SMI_BENCH_PROFILE_PREROLL") == "1":  # per-shape table of ONE pre-roll forward (with SMI_PROF_DUMP=1)
+        unet._engine.profile_enable(True)
+        pre_step.preroll(denoised, cond, 1, 3.0)
+        pp = unet._engine.profile_read()
+        unet._engine.profile_enable(False)
+        if rank == 0:
+            log("one pre-roll forward by class: " + json.dumps({k: round(v["ms"], 3) for k, v in pp.items()}))
     if rank == 0:
         log(f"pre-roll of {n_pre} forwards: {preroll_ms:.1f} ms")
 
