@@ -161,7 +161,12 @@ class EulerAncestralDiscreteScheduler:
         # this rank's rows are taken, so W ranks consume the control RNG like one rank at the global batch
         rank, world = getattr(self, "dp_shard", (0, 1))
         from .parallel import shard_noise
-        noise = shard_noise(lambda shp: torch.randn(shp, dtype=torch.float32, generator=generator),
+        # `noise_on_device` (or a device generator) draws on the sample's device instead, as diffusers' randn_tensor does
+        # when it is handed no CPU generator: no host draw and no 1 MB host-to-device copy per denoising step
+        on_dev = model_output.is_cuda and (getattr(self, "noise_on_device", False)
+                                           or (generator is not None and generator.device.type != "cpu"))
+        dev = model_output.device if on_dev else None
+        noise = shard_noise(lambda shp: torch.randn(shp, dtype=torch.float32, generator=generator, device=dev),
                             tuple(model_output.shape), rank, world)
         dt = sigma_down - sigma
         if self.prediction_type == "epsilon":
@@ -233,7 +238,9 @@ def create_noise_scheduler(scheduler_name: AVAILABLE_SCHEDULERS = "ddpm", predic
     if name == "lms":
         return LMSDiscreteScheduler(prediction_type=prediction_type)
     if name == "euler_a":
-        return EulerAncestralDiscreteScheduler(prediction_type=prediction_type)
+        s = EulerAncestralDiscreteScheduler(prediction_type=prediction_type)
+        s.noise_on_device = os.environ.get("SMI_DEVICE_NOISE", "0") == "1"
+        return s
     raise ValueError(f"Unknown scheduler name: {name}")
 
 

@@ -388,6 +388,37 @@ def test_step_ops_match_torch(lib):
     torch.testing.assert_close(x, 0.9 * xr - 0.2 * e + 0.05 * nz, rtol=1e-6, atol=1e-6)
 
 
+def test_euler_a_step_draws_its_noise_on_the_device_when_asked():
+    """EulerAncestralDiscreteScheduler.step with `noise_on_device` (or a device generator): the ancestral noise is the
+    device generator's randn of the sample's shape (what diffusers' randn_tensor does without a CPU generator), the
+    update is x + eps dt + noise sigma_up; the default stays the host draw the CPU oracle shares."""
+    import sliders_conceptmod_amd.model_util as MU
+    s = MU.create_noise_scheduler("euler_a")
+    s.set_timesteps(12)
+    t = s.timesteps[3]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x, e = torch.randn(2, 4, 16, 16, device="cuda", generator=g), torch.randn(2, 4, 16, 16, device="cuda", generator=g)
+    sig, sig_to = float(s.sigmas[3]), float(s.sigmas[4])
+    up = (sig_to ** 2 * (sig ** 2 - sig_to ** 2) / sig ** 2) ** 0.5
+    down = (sig_to ** 2 - up ** 2) ** 0.5
+    g1, g2 = torch.Generator(device="cuda").manual_seed(9), torch.Generator(device="cuda").manual_seed(9)
+    got = s.step(e, t, x, generator=g1).prev_sample
+    nz = torch.randn(x.shape, device="cuda", generator=g2)
+    torch.testing.assert_close(got, x + e * (down - sig) + nz * up, rtol=1e-6, atol=1e-6)
+    s.noise_on_device = True
+    torch.cuda.manual_seed(11)
+    got = s.step(e, t, x).prev_sample
+    torch.cuda.manual_seed(11)
+    nz = torch.randn(x.shape, device="cuda")
+    torch.testing.assert_close(got, x + e * (down - sig) + nz * up, rtol=1e-6, atol=1e-6)
+    s.noise_on_device = False
+    torch.manual_seed(3)
+    got = s.step(e, t, x).prev_sample
+    torch.manual_seed(3)
+    nz = torch.randn(x.shape).cuda()
+    torch.testing.assert_close(got, x + e * (down - sig) + nz * up, rtol=1e-6, atol=1e-6)
+
+
 def test_gemm_generations_are_bit_identical_per_epilogue_class():
     """The tile autotuner (csrc/gemm.hip) may serve a (shape, epilogue) key with any kernel generation / tile layout;
     that is only sound while they all produce the SAME BITS.  One op per key class -- full LoRA epilogue (bias + residual
