@@ -1157,7 +1157,7 @@ struct smi_engine {
     Ten* y = new_ten(x->rows, C, x->n, x->H, x->W);
     float* ab = alloc_f32((size_t)2 * x->n * C);
     float* mr = alloc_f32((size_t)x->n * G * 2);
-    const size_t npart = (size_t)x->n * gn_num_chunks(HW) * G * 2;
+    const size_t npart = gn_partial_floats(x->n, HW, G);
     float* part = alloc_f32(npart);
     RUNP(SMI_PROF_NORM, 0.0, 4.0 * x->rows * x->cols, launch_groupnorm_fwd(dtype, x->p, nm.gamma, nm.beta, y->p, ab, mr, part, x->n, HW, C, G, nm.eps, silu ? 1 : 0,
                              stream));

@@ -95,15 +95,16 @@ int launch_attn_bwd(const AttnParams& p, hipStream_t stream);
 // normalisation
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm over [Nb, HW, C]; writes per-(n,c) affine a,b (f32 [Nb,C] each: y = x*a + b) into `ab` ([2,Nb,C]) and
-// y = (silu?)(x*a+b).  `partial` is scratch f32 [Nb, nchunk, G, 2], nchunk from gn_num_chunks(HW).
+// y = (silu?)(x*a+b).  `partial` is scratch f32, gn_partial_floats(Nb, HW, G) long ([Nb, nchunk, G, 2], nchunk from gn_num_chunks(HW), + the fold).
 int gn_num_chunks(int HW);
+size_t gn_partial_floats(int Nb, int HW, int G);  // floats of `partial` scratch (chunk partials + their fold for maps > 128 x 128)
 // ab: [2][Nb][C] -- a = ab, b = ab + Nb*C.  The backward takes the two halves as separate pointers so that it can run
 // on a sample sub-range of a larger forward batch.
 int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* ab,
                          float* mean_rstd, float* partial, int Nb, int HW, int C, int G, float eps, int silu,
                          hipStream_t stream);
 // dx for y = silu?(GN(x)); needs x, gamma, beta, ab and mean_rstd from the forward.
-// `partial`: scratch f32 [Nb*nchunk*G*2 + 2*Nb*C]
+// `partial`: scratch f32, gn_partial_floats(Nb, HW, G) long
 // `add` (optional, may alias dx): gradient already accumulated for x, added in the same pass
 int launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const void* beta,
                          const float* a, const float* b, const float* mean_rstd, const void* add, void* dx,

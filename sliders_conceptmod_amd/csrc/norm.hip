@@ -16,7 +16,12 @@ namespace {
 // rows per chunk: at most 64 chunks per sample (the apply kernels re-reduce the chunk partials), at least 16 rows
 // (the 32x32 maps then still give 64 workgroups per sample).  Depends on HW only, so a sample's arithmetic does not
 // depend on the batch it travels in.
+// Maps beyond 128 x 128 (the VAE encoder: 1024 x 1024 x 128 channels of ONE image) get 256-row chunks instead -- 64
+// workgroups on 256 CUs ran those at 0.64 TB/s -- and their partials are folded down to 64 slots by gn_fold_kernel
+// before the apply kernels re-reduce them.
+constexpr int GN_MAX_SLOTS = 64;
 __host__ __device__ inline int gn_rows_per_chunk(int HW) {
+  if (HW > 16384) return 256;
   const int r = (HW + 63) / 64;
   return r < 16 ? 16 : (r + 15) / 16 * 16;
 }
@@ -128,6 +133,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   }
 }
 
+// partial [Nb][nchunk][G][2] -> folded [Nb][GN_MAX_SLOTS][G][2]: slot s = sum of chunks [s per, (s + 1) per) in order
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ partial, float* __restrict__ folded,
+                                                      int nchunk, int G2) {
+  const int n = blockIdx.y, s = blockIdx.x;
+  const int per = (nchunk + GN_MAX_SLOTS - 1) / GN_MAX_SLOTS;
+  const int c0 = s * per, c1 = min(nchunk, c0 + per);
+  for (int t = threadIdx.x; t < G2; t += 256) {
+    float a = 0.f;
+    for (int c = c0; c < c1; ++c) a += partial[((int64_t)n * nchunk + c) * G2 + t];
+    folded[((int64_t)n * GN_MAX_SLOTS + s) * G2 + t] = a;
+  }
+}
+
 // MODE 0: y = silu?(x*a+b).   MODE 1: dx = a*dz + c2*x + c3 (+ add).
 // Grid (chunk, n) as the partial kernel.  Head: the chunk partials of sample n -> per-group statistics in LDS
 // (8 lanes per group walk the partials, xor tree: fixed order, deterministic), then the rows of this chunk.
@@ -138,6 +156,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        float* __restrict__ bb, float* __restrict__ mean_rstd,
                                                        const T* add, T* out, int Nb,
                                                        int HW, int C, int G, int nchunk, float eps) {
+  // nchunk = slots of `partial` per sample (the grid's chunk count, or GN_MAX_SLOTS after a fold)
   extern __shared__ float st[];  // [G][2]: MODE 0 (mean, rstd); MODE 1 (c2, c3)
   const GnGeom gg = gn_geom(C);
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -364,6 +383,14 @@ inline int ew_grid(int64_t n_threads) {
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// more than GN_MAX_SLOTS chunks per sample: fold them into the slots behind the raw partials; returns what to re-reduce
+inline const float* gn_fold(float* partial, int Nb, int nchunk, int G, hipStream_t st) {
+  if (nchunk <= GN_MAX_SLOTS) return partial;
+  float* folded = partial + (size_t)Nb * nchunk * G * 2;
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(GN_MAX_SLOTS, Nb), dim3(256), 0, st, partial, folded, nchunk, G * 2);
+  return folded;
+}
+
 template <typename T>
 int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* ab, float* mean_rstd, float* partial,
              int Nb, int HW, int C, int G, float eps, int silu, hipStream_t st) {
@@ -373,12 +400,14 @@ int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float*
   hipLaunchKernelGGL((gn_partial_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x, nullptr,
                      nullptr, nullptr, ab, ab, partial, Nb, HW, C, G, nchunk);
   const size_t sa = (size_t)G * 2 * sizeof(float);
+  const float* red = gn_fold(partial, Nb, nchunk, G, st);
+  const int nslot = nchunk > GN_MAX_SLOTS ? GN_MAX_SLOTS : nchunk;
   if (silu)
     hipLaunchKernelGGL((gn_apply_kernel<T, 0, true>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, nullptr,
-                       (const T*)gamma, (const T*)beta, partial, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, Nb, HW, C, G, nchunk, eps);
+                       (const T*)gamma, (const T*)beta, red, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, Nb, HW, C, G, nslot, eps);
   else
     hipLaunchKernelGGL((gn_apply_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, nullptr,
-                       (const T*)gamma, (const T*)beta, partial, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, Nb, HW, C, G, nchunk, eps);
+                       (const T*)gamma, (const T*)beta, red, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, Nb, HW, C, G, nslot, eps);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -401,12 +430,14 @@ int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta,
   float* abp = const_cast<float*>(aa);
   float* bbp = const_cast<float*>(bb);
   float* mrp = const_cast<float*>(mean_rstd);
+  const float* red = gn_fold(partial, Nb, nchunk, G, st);
+  const int nslot = nchunk > GN_MAX_SLOTS ? GN_MAX_SLOTS : nchunk;
   if (silu)
     hipLaunchKernelGGL((gn_apply_kernel<T, 1, true>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, (const T*)dy,
-                       (const T*)gamma, (const T*)beta, partial, abp, bbp, mrp, (const T*)add, (T*)dx, Nb, HW, C, G, nchunk, 0.f);
+                       (const T*)gamma, (const T*)beta, red, abp, bbp, mrp, (const T*)add, (T*)dx, Nb, HW, C, G, nslot, 0.f);
   else
     hipLaunchKernelGGL((gn_apply_kernel<T, 1, false>), dim3(nchunk, Nb), dim3(256), sa, st, (const T*)x, (const T*)dy,
-                       (const T*)gamma, (const T*)beta, partial, abp, bbp, mrp, (const T*)add, (T*)dx, Nb, HW, C, G, nchunk, 0.f);
+                       (const T*)gamma, (const T*)beta, red, abp, bbp, mrp, (const T*)add, (T*)dx, Nb, HW, C, G, nslot, 0.f);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -414,6 +445,10 @@ int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta,
 }  // namespace
 
 int gn_num_chunks(int HW) { return (HW + gn_rows_per_chunk(HW) - 1) / gn_rows_per_chunk(HW); }
+size_t gn_partial_floats(int Nb, int HW, int G) {
+  const int nchunk = gn_num_chunks(HW);
+  return (size_t)Nb * (nchunk + (nchunk > GN_MAX_SLOTS ? GN_MAX_SLOTS : 0)) * G * 2;
+}
 
 int launch_groupnorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* ab,
                          float* mean_rstd, float* partial, int Nb, int HW, int C, int G, float eps, int silu,

@@ -271,14 +271,16 @@ def test_attention_rescale_branch_with_spiked_key(lib, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("nb,HW,Cc,G,silu", [(2, 256, 320, 32, 1), (3, 64, 64, 16, 0), (2, 1000, 2560, 32, 1),
+@pytest.mark.parametrize("nb,HW,Cc,G,silu", [(2, 256, 320, 32, 1), (3, 64, 64, 16, 0), (2, 1000, 2560, 32, 1), (1, 160 * 160, 128, 32, 1),
+                                                     (2, 16384 + 40, 64, 32, 0),
                                              (1, 4096, 640, 32, 1), (2, 100, 1920, 32, 0)])
 def test_groupnorm_forward_backward(lib, dt, nb, HW, Cc, G, silu):
     x = rnd(nb, HW, Cc, dt=dt, seed=1) * 2 + 0.5
     gamma, beta = (1 + 0.1 * rnd(Cc, dt=dt, seed=2)).to(dt), rnd(Cc, dt=dt, scale=0.1, seed=3)
     dy = rnd(nb, HW, Cc, dt=dt, seed=4)
     y, dx = torch.empty_like(x), torch.empty_like(x)
-    nchunk = (HW + 63) // 64
+    # chunk partials: <= 64 chunks of >= 16 rows up to 128 x 128 maps; 256-row chunks + a 64-slot fold beyond (norm.hip)
+    nchunk = (HW + 63) // 64 if HW <= 16384 else (HW + 255) // 256 + 64
     scratch = torch.empty(2 * nb * Cc + nb * G * 2 + nb * nchunk * G * 2 + 2 * nb * Cc + 64, device="cuda")
     chk(lib, lib.smi_op_groupnorm(dcode(dt), P(x), P(gamma), P(beta), P(y), P(dy), P(dx), P(scratch), nb, HW, Cc, G,
                                   1e-5, silu, None))
