@@ -309,7 +309,11 @@ def image_workload(args, world, rank, rank_devices, unet, net, sched, cfg, model
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed_vae else None
         if ev:
             ev[0].record()
-        lat = {k: sf * vae.encode(img[k]).latent_dist.sample(None) for k in img}   # I/train_util.py:213-222
+        # I/train_util.py:213-222 per image; both images in ONE batched encode, sampled per image in the reference's order
+        # (train_util.get_noisy_image_pair, what train_lora_scale_xl.py runs)
+        keys = list(img)
+        dist = vae.encode(torch.cat([img[k] for k in keys])).latent_dist
+        lat = {k: sf * dist.rows(i * B, (i + 1) * B).sample(None) for i, k in enumerate(keys)}
         noised = {k: sched.add_noise(lat[k], noise, timestep.reshape(1)) for k in img}  # same seed -> same noise (:224-247)
         if ev:
             ev[1].record()

@@ -161,12 +161,11 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
         seed = random.randint(0, 2 * 15)
         if images:  # the reference's path: resize, VAE-encode and noise both images with the same seed (:220-247)
             from PIL import Image
-            pair = []
-            for f in (f_low, f_high):
-                img = Image.open(os.path.join(folder_main, f, name)).resize(size)
-                pair.append(train_util.get_noisy_image(img, vae, torch.manual_seed(seed), unet, noise_scheduler,
-                                                       start_timesteps=0, total_timesteps=timesteps_to))
-            (nl, noise_low), (nh, noise_high) = pair
+            imgs = [Image.open(os.path.join(folder_main, f, name)).resize(size) for f in (f_low, f_high)]
+            # one batched VAE encode for both; the per-image `torch.manual_seed(seed)` of the reference stays per image
+            (nl, noise_low), (nh, noise_high) = train_util.get_noisy_image_pair(
+                imgs, vae, lambda: torch.manual_seed(seed), unet, noise_scheduler, start_timesteps=0,
+                total_timesteps=timesteps_to)
         else:
             lat_low = _load_latent(os.path.join(folder_main, f_low, name)).unsqueeze(0).float()
             lat_high = _load_latent(os.path.join(folder_main, f_high, name)).unsqueeze(0).float()

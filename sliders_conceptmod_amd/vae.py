@@ -106,6 +106,12 @@ class DiagonalGaussianDistribution:
     def mode(self) -> torch.Tensor:
         return self.mean
 
+    def rows(self, lo: int, hi: int) -> "DiagonalGaussianDistribution":
+        """The posterior of samples [lo, hi) of a batched encode (train_util.get_noisy_image_pair)."""
+        d = object.__new__(DiagonalGaussianDistribution)
+        d.mean, d.logvar, d.std = self.mean[lo:hi], self.logvar[lo:hi], self.std[lo:hi]
+        return d
+
 
 class _EncoderOutput:
     def __init__(self, latent_dist):

@@ -84,6 +84,29 @@ def test_get_noisy_image_follows_the_reference_order():
     assert pv.config.scaling_factor == ov.cfg.scaling_factor
 
 
+@pytest.mark.parametrize("cfg,size", [("tiny", 64), ("sdxl", 256)])
+def test_get_noisy_image_pair_equals_one_call_per_image(cfg, size):
+    """train_util.get_noisy_image_pair (one batched VAE encode for the two images of an image-slider step) against the
+    reference's one call per image with `torch.manual_seed(seed)` in front of each: same posterior samples (the device RNG
+    is re-seeded per image either way), same noise, same noised latents.  A sample's arithmetic does not depend on the batch
+    it is encoded in, so the results are compared at rounding level, and bit for bit where no launch changes its K split."""
+    import sliders_conceptmod_amd.model_util as MU
+    from sliders_conceptmod_amd import train_util as TU
+    _, pv = pair(OV.tiny_vae_config() if cfg == "tiny" else OV.sdxl_vae_config(), torch.float16)
+    g = torch.Generator().manual_seed(3)
+    imgs = [(torch.rand(size, size, 3, generator=g) * 255).to(torch.uint8).numpy() for _ in range(2)]
+    sch = MU.create_noise_scheduler("ddim")
+    sch.set_timesteps(50)
+    one = [TU.get_noisy_image(im, pv, torch.manual_seed(21), None, sch, total_timesteps=17) for im in imgs]
+    two = TU.get_noisy_image_pair(imgs, pv, lambda: torch.manual_seed(21), None, sch, total_timesteps=17)
+    for (a, na), (b, nb) in zip(one, two):
+        torch.testing.assert_close(na, nb, rtol=0, atol=0)
+        e = rel(b, a)
+        print(f"{cfg} {size}px pair vs single encode: rel diff {e:.2e}, bit-equal {bool((a == b).all())}")
+        assert e < 2e-3, e
+    assert rel(one[0][0], one[1][0]) > 1e-2  # the two images do differ
+
+
 @pytest.mark.parametrize("xl", [True, False])
 def test_image_slider_trainer_encodes_image_folders(tmp_path, xl):
     """train_lora_scale_xl.train() on folders of PNG pairs (the reference's data layout): resize, VAE-encode on the engine,
