@@ -753,11 +753,9 @@ int fwd_t(const AttnParams& p, hipStream_t st) {
 
 template <typename T, int DP, int WHICH, int NSD>
 int dkv_launch(const AttnParams& p, dim3 grid, size_t sm, hipStream_t st) {
-  static bool attr_set = false;  // (per instantiation)
-  if (!attr_set && sm > 65536) {
-    SMI_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DP, WHICH, NSD>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    attr_set = true;
+  if (sm > 65536) {
+    static DynLdsOnce once;  // (per instantiation, per device)
+    if (int rc = once.set((const void*)attn_bwd_dkv_kernel<T, DP, WHICH, NSD>, (int)sm)) return rc;
   }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, WHICH, NSD>), grid, dim3(256), sm, st, p);
   return 0;

@@ -605,11 +605,9 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = 64 * WM;
   constexpr int NW = (NL >= 2 ? 4 : 2) * WM;
   constexpr int SMEM = (DEEP ? 4 : 2) * (BM + BN) * BK * 2;
-  static bool attr_done = false;
-  if (!attr_done && SMEM > 65536) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, CONV, WM, NL, DEEP>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
+  if (SMEM > 65536) {
+    static DynLdsOnce once;  // (per instantiation, per device)
+    if (int rc = once.set((const void*)gemm_glds_kernel<T, CONV, WM, NL, DEEP>, SMEM)) return rc;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN) * (p.ksplit > 1 ? p.ksplit : 1);
   hipLaunchKernelGGL((gemm_glds_kernel<T, CONV, WM, NL, DEEP>), dim3(grid), dim3(NW * 64), SMEM, stream, p);

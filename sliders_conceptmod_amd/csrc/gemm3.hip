@@ -422,12 +422,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
 
 template <typename T, bool CONV>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    SMI_HIP(hipFuncSetAttribute((const void*)gemm_8ph_kernel<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM3));
-    attr_done = true;
-  }
+  static DynLdsOnce once;  // (per instantiation, per device)
+  if (int rc = once.set((const void*)gemm_8ph_kernel<T, CONV>, SMEM3)) return rc;
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
   hipLaunchKernelGGL((gemm_8ph_kernel<T, CONV>), dim3(grid), dim3(512), SMEM3, stream, p);
   SMI_HIP(hipGetLastError());

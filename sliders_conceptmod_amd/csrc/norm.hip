@@ -274,108 +274,197 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, C <= 8*64*LN_MAXV
+// LayerNorm: a wave owns R consecutive rows (C <= 8*64*LN_MAXV); NV = vectors of 8 elements per lane is a template
+// parameter, so a 1280-wide row is 3 loads per lane with no dead registers; the loads of all R rows are issued up front
+// and their reductions interleave.  The wave reduction runs on DPP within 16-lane rows (quad swaps, half mirror, mirror)
+// and four v_readlane across them instead of six LDS-crossbar shuffles.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 4;  // C <= 2048
 
-template <typename T, int MODE>  // 0 fwd, 1 bwd
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// the same sum in every lane; fixed order
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+template <typename T, int MODE, int NV, int R>  // MODE 0 fwd, 1 bwd
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                  const T* __restrict__ gamma, const T* beta, T* out,
                                                  float* __restrict__ mean_rstd, int M, int C, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
   const int nvec = C / 8;
-  float xv[LN_MAXV][8];
+  const float inv_c = 1.f / (float)C;
+  float xv[R][NV][8];
+  Pack8<T> dv[MODE == 1 ? R : 1][NV];
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    const int v = lane + 64 * j;
-    if (v < nvec) {
+  for (int r = 0; r < R; ++r) {
+    const int row = min(row0 + r, M - 1);  // a tail row re-reads the last row; its stores are masked below
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int v = lane + 64 * j;
       Pack8<T> t;
-      t.u = *reinterpret_cast<const u32x4*>(x + (int64_t)row * C + v * 8);
+      if (v < nvec) {
+        t.u = *reinterpret_cast<const u32x4*>(x + (int64_t)row * C + v * 8);
+        if (MODE == 1) dv[r][j].u = *reinterpret_cast<const u32x4*>(dy + (int64_t)row * C + v * 8);
+      } else {
+        t.u = u32x4{0u, 0u, 0u, 0u};
+        if (MODE == 1) dv[r][j].u = u32x4{0u, 0u, 0u, 0u};
+      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xv[j][e] = to_f(t.e[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xv[j][e] = 0.f;
+      for (int e = 0; e < 8; ++e) xv[r][j][e] = to_f(t.e[e]);
     }
   }
-  float mean, rstd;
   if (MODE == 0) {
-    float s = 0.f;
+    float mean[R], rstd[R];
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j)
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += xv[j][e];
-    mean = wave_sum(s) / (float)C;
-    float sq = 0.f;
+      for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-      const int v = lane + 64 * j;
-      if (v < nvec) {
+        for (int e = 0; e < 8; ++e) s += xv[r][j][e];
+      mean[r] = s;
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = xv[j][e] - mean;
-          sq += d * d;
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum_dpp(mean[r]) * inv_c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if (lane + 64 * j < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = xv[r][j][e] - mean[r];
+            sq += d * d;
+          }
         }
       }
-    }
-    rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-    if (lane == 0) {
-      mean_rstd[(int64_t)row * 2] = mean;
-      mean_rstd[(int64_t)row * 2 + 1] = rstd;
+      rstd[r] = sq;
     }
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(wave_sum_dpp(rstd[r]) * inv_c + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
       const int v = lane + 64 * j;
       if (v < nvec) {
-        Pack8<T> g8, b8, o;
+        Pack8<T> g8, b8;
         g8.u = *reinterpret_cast<const u32x4*>(gamma + v * 8);
         b8.u = *reinterpret_cast<const u32x4*>(beta + v * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>((xv[j][e] - mean) * rstd * to_f(g8.e[e]) + to_f(b8.e[e]));
-        *reinterpret_cast<u32x4*>(out + (int64_t)row * C + v * 8) = o.u;
+        for (int r = 0; r < R; ++r) {
+          if (row0 + r < M) {
+            Pack8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              o.e[e] = from_f<T>((xv[r][j][e] - mean[r]) * rstd[r] * to_f(g8.e[e]) + to_f(b8.e[e]));
+            *reinterpret_cast<u32x4*>(out + (int64_t)(row0 + r) * C + v * 8) = o.u;
+          }
+        }
       }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (row0 + r < M) {
+          mean_rstd[(int64_t)(row0 + r) * 2] = mean[r];
+          mean_rstd[(int64_t)(row0 + r) * 2 + 1] = rstd[r];
+        }
     }
   } else {
-    mean = mean_rstd[(int64_t)row * 2];
-    rstd = mean_rstd[(int64_t)row * 2 + 1];
-    float dg[LN_MAXV][8];
-    float s1 = 0.f, s2 = 0.f;
+    float dg[R][NV][8];
+    float s1[R], s2[R], rs[R];
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-      const int v = lane + 64 * j;
-      if (v < nvec) {
-        Pack8<T> g8, d8;
-        g8.u = *reinterpret_cast<const u32x4*>(gamma + v * 8);
-        d8.u = *reinterpret_cast<const u32x4*>(dy + (int64_t)row * C + v * 8);
+    for (int r = 0; r < R; ++r) {
+      const int row = min(row0 + r, M - 1);
+      const float mean = mean_rstd[(int64_t)row * 2];
+      rs[r] = mean_rstd[(int64_t)row * 2 + 1];
+      s1[r] = s2[r] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xv[j][e] = (xv[j][e] - mean) * rstd;  // xhat
-          dg[j][e] = to_f(d8.e[e]) * to_f(g8.e[e]);
-          s1 += dg[j][e];
-          s2 += dg[j][e] * xv[j][e];
+      for (int j = 0; j < NV; ++j) {
+        const int v = lane + 64 * j;
+        if (v < nvec) {
+          Pack8<T> g8;
+          g8.u = *reinterpret_cast<const u32x4*>(gamma + v * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xv[r][j][e] = (xv[r][j][e] - mean) * rs[r];  // xhat
+            dg[r][j][e] = to_f(dv[r][j].e[e]) * to_f(g8.e[e]);
+            s1[r] += dg[r][j][e];
+            s2[r] += dg[r][j][e] * xv[r][j][e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dg[r][j][e] = 0.f;
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dg[j][e] = 0.f;
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-      const int v = lane + 64 * j;
-      if (v < nvec) {
-        Pack8<T> o, ad;
-        if (beta) ad.u = *reinterpret_cast<const u32x4*>(beta + (int64_t)row * C + v * 8);  // bwd: beta = `add`
+    for (int r = 0; r < R; ++r) {
+      s1[r] = wave_sum_dpp(s1[r]) * inv_c;
+      s2[r] = wave_sum_dpp(s2[r]) * inv_c;
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          o.e[e] = from_f<T>(rstd * (dg[j][e] - s1 - xv[j][e] * s2) + (beta ? to_f(ad.e[e]) : 0.f));
-        *reinterpret_cast<u32x4*>(out + (int64_t)row * C + v * 8) = o.u;
+    for (int r = 0; r < R; ++r) {
+      if (row0 + r >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int v = lane + 64 * j;
+        if (v < nvec) {
+          Pack8<T> o, ad;
+          if (beta) ad.u = *reinterpret_cast<const u32x4*>(beta + (int64_t)(row0 + r) * C + v * 8);  // bwd: beta = `add`
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o.e[e] = from_f<T>(rs[r] * (dg[r][j][e] - s1[r] - xv[r][j][e] * s2[r]) + (beta ? to_f(ad.e[e]) : 0.f));
+          *reinterpret_cast<u32x4*>(out + (int64_t)(row0 + r) * C + v * 8) = o.u;
+        }
       }
     }
   }
+}
+
+// rows per wave: 2 once there are enough rows to fill the chip twice over (16 waves per SIMD), else 1
+template <typename T, int MODE>
+int ln_launch(const T* x, const T* dy, const T* gamma, const T* beta, T* out, float* mean_rstd, int M, int C, float eps,
+              hipStream_t stream) {
+  const int nv = (C / 8 + 63) / 64;
+  static const int force_r = []() { const char* e = getenv("SMI_LN_ROWS"); return e ? atoi(e) : 0; }();
+  const int R = force_r ? force_r : (MODE == 0 && M >= 16384 ? 2 : 1);
+#define LN_GO(NV_, R_)                                                                                              \
+  hipLaunchKernelGGL((ln_kernel<T, MODE, NV_, R_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, stream, x, dy, gamma, beta, \
+                     out, mean_rstd, M, C, eps)
+  if (R == 2) {
+    switch (nv) {
+      case 1: LN_GO(1, 2); break;
+      case 2: LN_GO(2, 2); break;
+      case 3: LN_GO(3, 2); break;
+      default: LN_GO(4, 2); break;
+    }
+  } else {
+    switch (nv) {
+      case 1: LN_GO(1, 1); break;
+      case 2: LN_GO(2, 1); break;
+      case 3: LN_GO(3, 1); break;
+      default: LN_GO(4, 1); break;
+    }
+  }
+#undef LN_GO
+  SMI_HIP(hipGetLastError());
+  return 0;
 }
 
 inline int ew_grid(int64_t n_threads) {
@@ -472,29 +561,21 @@ int launch_groupnorm_bwd(int dtype, const void* x, const void* dy, const void* g
 int launch_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean_rstd,
                          int M, int C, float eps, hipStream_t stream) {
   SMI_CHECK(C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "layernorm: C=%d unsupported", C);
-  const int grid = cdiv(M, 4);
   if (dtype == DT_F16)
-    hipLaunchKernelGGL((ln_kernel<f16, 0>), dim3(grid), dim3(256), 0, stream, (const f16*)x, nullptr,
-                       (const f16*)gamma, (const f16*)beta, (f16*)y, mean_rstd, M, C, eps);
-  else
-    hipLaunchKernelGGL((ln_kernel<bf16, 0>), dim3(grid), dim3(256), 0, stream, (const bf16*)x, nullptr,
-                       (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean_rstd, M, C, eps);
-  SMI_HIP(hipGetLastError());
-  return 0;
+    return ln_launch<f16, 0>((const f16*)x, nullptr, (const f16*)gamma, (const f16*)beta, (f16*)y, mean_rstd, M, C, eps,
+                             stream);
+  return ln_launch<bf16, 0>((const bf16*)x, nullptr, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean_rstd, M, C,
+                            eps, stream);
 }
 
 int launch_layernorm_bwd(int dtype, const void* x, const void* dy, const void* gamma, const float* mean_rstd,
                          const void* add, void* dx, int M, int C, hipStream_t stream) {
   SMI_CHECK(C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "layernorm: C=%d unsupported", C);
-  const int grid = cdiv(M, 4);
   if (dtype == DT_F16)
-    hipLaunchKernelGGL((ln_kernel<f16, 1>), dim3(grid), dim3(256), 0, stream, (const f16*)x, (const f16*)dy,
-                       (const f16*)gamma, (const f16*)add, (f16*)dx, const_cast<float*>(mean_rstd), M, C, 0.f);
-  else
-    hipLaunchKernelGGL((ln_kernel<bf16, 1>), dim3(grid), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy,
-                       (const bf16*)gamma, (const bf16*)add, (bf16*)dx, const_cast<float*>(mean_rstd), M, C, 0.f);
-  SMI_HIP(hipGetLastError());
-  return 0;
+    return ln_launch<f16, 1>((const f16*)x, (const f16*)dy, (const f16*)gamma, (const f16*)add, (f16*)dx,
+                             const_cast<float*>(mean_rstd), M, C, 0.f, stream);
+  return ln_launch<bf16, 1>((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, (const bf16*)add, (bf16*)dx,
+                            const_cast<float*>(mean_rstd), M, C, 0.f, stream);
 }
 
 }  // namespace smi

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 
 namespace smi {
 
@@ -161,5 +162,22 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
+// function ON the current device, and engines on several devices / host threads may share one process.
+// Use: `static DynLdsOnce once; if (int rc = once.set((const void*)kernel, bytes)) return rc;`
+struct DynLdsOnce {
+  std::mutex mu;
+  uint64_t done = 0;  // one bit per device ordinal
+  int set(const void* fn, int bytes) {
+    int dev = 0;
+    SMI_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1)) return 0;
+    SMI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < 64) done |= 1ull << dev;
+    return 0;
+  }
+};
 
 }  // namespace smi
