@@ -120,7 +120,11 @@ __global__ void lora_prep_kernel(const LoraPrepSite* __restrict__ sites, const f
 template <typename T, int R>
 __global__ __launch_bounds__(256) void lora_wgrad_grouped_partial_kernel(const WgradJob* __restrict__ jobs, int njobs) {
   __shared__ float red[256 * 8];
-  __shared__ float ps[256 * 32];  // the workgroup's rows of P (x row scale), staged once: [row][all segments' r columns]
+  // the workgroup's rows of P (x row scale), staged once: [row][all segments' r columns].  Sized by the rank class: the
+  // rank <= 4 class (three fused segments = 12 columns at most) keeps 20 KB of LDS per workgroup instead of 40 KB, i.e.
+  // 7 instead of 3 workgroups per CU in flight for a kernel that only waits on HBM
+  constexpr int PSW = R <= 4 ? 12 : 32;
+  __shared__ float ps[256 * PSW];
   __shared__ int jsel;
   if (threadIdx.x == 0) {  // last job whose first workgroup is <= blockIdx.x (jobs of one class are contiguous)
     int lo = 0, hi = njobs - 1;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void lora_wgrad_grouped_partial_kernel(const W
   // P is tiny (r floats per row) but was 17 load instructions per row and thread against ONE for X: stage the rows of
   // this workgroup in LDS (all segments' columns, row scale folded in) and read them back as LDS broadcasts
   const int pw = jb.seg_cols ? (jb.K / jb.seg_cols) * r : r;
-  const bool staged = pw <= 32 && jb.rows_per_wg <= 256;
+  const bool staged = pw <= PSW && jb.rows_per_wg <= 256;
   if (staged) {
     const int nrow = row1 - row0;
     for (int i = tid; i < nrow * pw; i += 256) {
