@@ -167,6 +167,7 @@ struct Resnet {
   Lin temb, sc;
   bool has_sc = false;
   bool has_temb = true;  // false in the VAE encoder
+  int64_t temb_col = 0;  // column offset of this resnet's time_emb_proj inside the grouped projection
 };
 struct TBlock {
   Norm n1, n2, n3;
@@ -293,6 +294,9 @@ struct smi_engine {
   Lin kv_all;
   bool kv_grouped = false;
   Ten* kv_all_out = nullptr;
+  Lin temb_all;  // every resnet's time_emb_proj stacked (they all read silu(emb)): one GEMM per pass
+  bool temb_grouped = false;
+  Ten* temb_all_out = nullptr;
 
   // model
   Conv conv_in, conv_out;
@@ -866,6 +870,7 @@ struct smi_engine {
       conv_out.Wg = wg;
     }
     build_kv_group();
+    build_temb_group();
     finish_lora();
     gscale = (float*)pack_alloc((3 * MAXS + 258) * sizeof(float));  // + [2 MAXS..): min, 1/min, min / scale_j (DoRA)
     samp_mult_dev = (float*)pack_alloc(2 * MAXS * sizeof(float));
@@ -910,6 +915,48 @@ struct smi_engine {
     kv_all.W = w;
     kv_all.in = D;
     kv_all.out = (int)total;
+  }
+
+  // every resnet's time_emb_proj reads the same silu(emb) [n, 1280]: stack them into ONE GEMM per pass (SD-1.x: 22
+  // launches of n <= 32 rows, each a split-K pair, -> one pair); the conv1 epilogues read their column block as a row
+  // vector with a leading dimension.  Only when no adaptor sits on a time_emb_proj (c3lier has one on each).
+  template <typename F>
+  void for_each_resnet(F f) {
+    for (auto& lv : down) for (auto& r : lv.res) f(r);
+    for (auto& r : mid.res) f(r);
+    for (auto& lv : up) for (auto& r : lv.res) f(r);
+  }
+  void build_temb_group() {
+    int64_t total = 0;
+    bool any_lora = false, same_in = true;
+    int in = 0;
+    for_each_resnet([&](Resnet& r) {
+      if (!r.has_temb) return;
+      r.temb_col = total;
+      total += r.temb.out;
+      any_lora |= r.temb.nsite > 0;
+      if (in == 0) in = r.temb.in;
+      same_in &= r.temb.in == in;
+    });
+    static const bool off = getenv("SMI_TEMB_GROUP") && atoi(getenv("SMI_TEMB_GROUP")) == 0;
+    temb_grouped = !off && !any_lora && same_in && total > 0 && total % 8 == 0;
+    if (!temb_grouped) return;
+    char* w = (char*)pack_alloc((size_t)total * in * esz());
+    char* b = (char*)pack_alloc((size_t)total * esz());
+    if (!dry && !err) (void)hipMemsetAsync(b, 0, (size_t)total * esz(), stream);  // (a projection without a bias adds zero)
+    for_each_resnet([&](Resnet& r) {
+      if (!r.has_temb || dry || err || !r.temb.W) return;
+      (void)hipMemcpyAsync(w + (size_t)r.temb_col * in * esz(), r.temb.W, (size_t)r.temb.out * in * esz(),
+                           hipMemcpyDeviceToDevice, stream);
+      if (r.temb.b)
+        (void)hipMemcpyAsync(b + (size_t)r.temb_col * esz(), r.temb.b, (size_t)r.temb.out * esz(),
+                             hipMemcpyDeviceToDevice, stream);
+    });
+    temb_all.name = "grouped time_emb_proj";
+    temb_all.W = w;
+    temb_all.b = b;
+    temb_all.in = in;
+    temb_all.out = (int)total;
   }
 
   // ---------------------------------------------------------------------------------------------------------
@@ -1317,7 +1364,7 @@ struct smi_engine {
   }
 
   // 3x3 conv (pad 1): mode 0 stride 1, 1 stride 2, 2 nearest-2x upsample then stride 1
-  Ten* conv3x3(Ten* x, const Conv& c, Ten* rowvec, Ten* res) {
+  Ten* conv3x3(Ten* x, const Conv& c, Ten* rowvec, Ten* res, int64_t ld_rowvec = 0) {
     const int Hin = x->H, Win = x->W;
     const int Hout = c.mode == 1 ? (Hin + 1) / 2 : (c.mode == 2 ? Hin * 2 : Hin);
     const int Wout = c.mode == 1 ? (Win + 1) / 2 : (c.mode == 2 ? Win * 2 : Win);
@@ -1345,6 +1392,7 @@ struct smi_engine {
     if (rowvec) {
       p.rowvec = rowvec->p;
       p.rows_per_vec = Hout * Wout;
+      p.ld_rowvec = ld_rowvec;
     }
     if (res) {
       p.res = res->p;
@@ -1555,8 +1603,20 @@ struct smi_engine {
 
   Ten* resnet(Ten* x, const Resnet& r, Ten* temb_act) {
     Ten* h = groupnorm(x, r.n1, true);
-    Ten* t = r.has_temb ? linear(temb_act, r.temb) : nullptr;
-    h = conv3x3(h, r.c1, t, nullptr);
+    Ten* t = nullptr;
+    int64_t ldt = 0;
+    if (r.has_temb && temb_all_out) {  // a column block of the grouped projection (no gradient flows into it)
+      tens->emplace_back();
+      t = &tens->back();
+      t->p = (char*)temb_all_out->p + (size_t)r.temb_col * esz();
+      t->rows = temb_all_out->rows;
+      t->cols = r.temb.out;
+      t->n = temb_all_out->n;
+      ldt = temb_all.out;
+    } else if (r.has_temb) {
+      t = linear(temb_act, r.temb);
+    }
+    h = conv3x3(h, r.c1, t, nullptr, ldt);
     h = groupnorm(h, r.n2, true);
     Ten* sc = r.has_sc ? linear(x, r.sc) : x;
     return conv3x3(h, r.c2, nullptr, sc);
@@ -1901,6 +1961,8 @@ struct smi_engine {
     ctx->arow0 = (int64_t)(n - n_ad) * ctx_len;
 
     if (kv_grouped) kv_all_out = linear(ctx, kv_all);
+    // (only while nothing upstream of emb is trained: the column-block views carry no gradient)
+    temb_all_out = (temb_grouped && !temb_act->ng) ? linear(temb_act, temb_all) : nullptr;
 
     // ---- conv_in (MFMA implicit GEMM on the 64-channel zero-padded latent)
     Ten* x0 = new_ten((int64_t)n * HW, 64, n, H, Wd_);

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     if (m >= p.M) continue;
     const bool lora_on = p.lora_r > 0 && m >= p.lora_row0;
     const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
-    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
+    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * (p.ld_rowvec ? p.ld_rowvec : (int64_t)p.N) : 0;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = bn0 + wn * 64 + ni * 16 + fq * 4;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmParams p, const 
     }
     if (p.rowvec) {
       Pack4<T> b;
-      b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.rowvec) + (int64_t)(m / p.rows_per_vec) * p.N + n);
+      b.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.rowvec) + (int64_t)(m / p.rows_per_vec) * (p.ld_rowvec ? p.ld_rowvec : (int64_t)p.N) + n);
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
     }

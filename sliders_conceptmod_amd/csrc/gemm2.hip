@@ -411,7 +411,7 @@ __global__ __launch_bounds__((NL >= 2 ? 4 : 2) * WM * 64) void gemm_glds_kernel(
     if (m >= p.M) continue;
     const bool lora_on = p.lora_r > 0 && m >= p.lora_row0;
     const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
-    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
+    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * (p.ld_rowvec ? p.ld_rowvec : (int64_t)p.N) : 0;
 #pragma unroll
     for (int q = 0; q < (NI + 1) / 2; ++q) {
       constexpr bool ODD = (NI & 1) != 0;

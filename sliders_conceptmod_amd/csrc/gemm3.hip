@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(GemmParams p) {
     if (m >= p.M) continue;
     const bool lora_on = p.lora_r > 0 && m >= p.lora_row0;
     const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
-    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * p.N : 0;
+    const int64_t vrow = p.rowvec ? (int64_t)(m / p.rows_per_vec) * (p.ld_rowvec ? p.ld_rowvec : (int64_t)p.N) : 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int nl = wc * 64 + q * 32 + fq * 8;

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
         if (p.rowvec) {
           Pack8<T> b;
           b.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.rowvec) +
-                                                (int64_t)(m / p.rows_per_vec) * p.N + n);
+                                                (int64_t)(m / p.rows_per_vec) * (p.ld_rowvec ? p.ld_rowvec : (int64_t)p.N) + n);
 #pragma unroll
           for (int j = 0; j < 8; ++j) vv[j] += to_f(b.e[j]);
         }

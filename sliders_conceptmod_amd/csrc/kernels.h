@@ -28,6 +28,7 @@ struct GemmParams {
   int64_t ldr = 0;
   const void* rowvec = nullptr;  // T [M / rows_per_vec, N]
   int rows_per_vec = 1;
+  int64_t ld_rowvec = 0;         // row stride of rowvec in elements (0 = N): a column block of a wider matrix
   // LoRA rank-r delta: + lora_scale * sum_q xa[m*ld_xa + seg*r + q] * up[n*up_sn + q*up_sq], seg = n / lora_seg.
   // Forward: xa = x*A^T, up = lora_up.weight [N, r] (up_sn = r, up_sq = 1); with fused q|k|v projections the three
   // [C, r] up matrices are adjacent in the flat buffer and lora_seg = C selects each column block's own xa.

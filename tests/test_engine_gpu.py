@@ -466,3 +466,40 @@ def test_per_sample_multipliers_equal_separate_passes(model):
     eng2 = pu2._ensure_engine(4, 16, 16, 77)
     with pytest.raises(_native.SmiError, match="per-sample multipliers"):
         eng2.forward(xc, 499.0, cc, te, ti, flat2[:nd2], flat2[nd2:], [s, s, -s, -s], False)
+
+
+@pytest.mark.parametrize("model", list(CFGS))
+def test_grouped_time_emb_proj_equals_one_gemm_per_resnet(model):
+    """engine.hip build_temb_group: every resnet's time_emb_proj stacked into ONE GEMM per pass, conv1 reading its column
+    block as a row vector with a leading dimension -- against `SMI_TEMB_GROUP=0` (one GEMM per resnet), in two processes
+    (the switch is read once).  Same products, different split-K partition of the K loop: rounding-level agreement, and
+    the adapted pass with gradients must agree as well (no gradient flows into the views)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import json, sys, torch
+sys.path.insert(0, {root!r})
+from tests.test_engine_gpu import build_pair, inputs, cuda_add
+ocfg, ou, onet, pu, pnet = build_pair({model!r}, torch.float16)
+x, ctx, add = inputs(ocfg, 2, 16)
+pnet.__enter__()
+eps = pu(x.cuda(), 499.0, encoder_hidden_states=ctx.cuda(), added_cond_kwargs=cuda_add(add)).sample
+eps.square().mean().backward()
+g = torch.cat([p.grad.flatten() for p in pnet.parameters() if p.grad is not None])
+print(json.dumps({{"eps": eps.flatten().tolist(), "g": g[:: max(1, g.numel() // 4096)].tolist()}}))
+"""
+    res = {}
+    for arm in ("1", "0"):
+        env = dict(os.environ, SMI_TEMB_GROUP=arm)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        res[arm] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = torch.tensor(res["1"]["eps"]), torch.tensor(res["0"]["eps"])
+    ga, gb = torch.tensor(res["1"]["g"]), torch.tensor(res["0"]["g"])
+    e, eg = rel(a, b), rel(ga, gb)
+    print(f"{model}: grouped vs per-resnet time_emb_proj: eps rel diff {e:.2e}, LoRA-gradient rel diff {eg:.2e}")
+    assert e < 1e-3 and eg < 5e-3, (e, eg)
+    assert float(gb.abs().max()) > 0
