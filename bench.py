@@ -37,6 +37,8 @@ CONFIGS = {
     "tiny_sdxl": ("tiny_sdxl", 128, 2, 4, "fp16", "euler_a", 0.2, 1e-4, 1e-6),
     # the shipped SD-1.x default network type (T/data/config.yaml:7): conv + time_emb_proj + attention adaptors
     "sd14_512_b1_r4_c3lier": ("sd1x", 512, 1, 4, "fp16", "ddim", 0.0, 2e-4, 1e-2),
+    # `--peft_type dora` of train_lora_xl.py (T/dora.py): the headline shape with DoRA modules instead of LoRA
+    "sdxl_1024_b2_r4_dora": ("sdxl", 1024, 2, 4, "fp16", "euler_a", 0.2, 1e-4, 1e-6),
     # BASELINE configs[4] per-GPU unit: SD-XL image slider (train_lora-scale-xl.py), one before/after pair per step at
     # 1024^2, scales +1 / -1: VAE-encode both images, noise them, two adapted UNet passes (+s / -s) with their two backward
     # passes accumulating one LoRA gradient, AdamW.  Measured by the same JSON contract; `config.step` says what a step is.
@@ -472,8 +474,13 @@ def main():
     torch.manual_seed(1)
     c3lier = args.config.endswith("_c3lier")
     targets = list(L.DEFAULT_TARGET_REPLACE) + (list(L.UNET_TARGET_REPLACE_MODULE_CONV) if c3lier else [])
-    net = L.LoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn",
-                        target_replace=targets).to("cuda")
+    dora = args.config.endswith("_dora")
+    if dora:
+        from sliders_conceptmod_amd.dora import DoRANetwork
+        net = DoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn").to("cuda")
+    else:
+        net = L.LoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn",
+                            target_replace=targets).to("cuda")
     with torch.no_grad():  # non-zero up weights so no kernel can short-circuit
         net.flat_up.copy_(torch.randn(net.flat_up.shape, generator=torch.Generator().manual_seed(2)) * 1e-2)
     sched = MU.create_noise_scheduler(sched_name)
@@ -591,7 +598,7 @@ def main():
             "dtype": dt_name, "data": "synthetic",
             "config": {"workload": args.config, "unet": model, "resolution": res, "per_gpu_batch": B,
                        "unet_batch": B if args.skip_dead_cfg_half else 2 * B, "global_batch": B * world,
-                       "lora_rank": lrank, "train_method": "noxattn", "network_type": "c3lier" if c3lier else "lierla",
+                       "lora_rank": lrank, "train_method": "noxattn", "network_type": "dora" if dora else ("c3lier" if c3lier else "lierla"),
                        "lora_params": int(net.flat.numel()),
                        "scheduler": sched_name, "parallelism": f"dp{world}", "pre_roll": "excluded",
                        "skip_dead_cfg_half": bool(args.skip_dead_cfg_half),

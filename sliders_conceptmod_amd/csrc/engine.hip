@@ -274,15 +274,31 @@ struct smi_engine {
   std::vector<void*> dora_dWt;  // [in, out] per site
   DoraSite* dora_sites_dev = nullptr;
   float bw_mult = 0.f;
-  void dora_prepare(const float* down, const float* up, float m) {
+  // what the delta-weight buffers currently hold: set by dora_prepare, so that the backward of a saved forward does not
+  // rebuild what that forward built (nothing ran in between); `with_t`: the transposed copies for the dX GEMMs exist too
+  const float* dora_ready_down = nullptr;
+  const float* dora_ready_up = nullptr;
+  float dora_ready_mult = 0.f;
+  bool dora_ready_t = false;
+  void dora_prepare(const float* down, const float* up, float m, bool with_t, bool reuse) {
     if (dora_sites.empty() || dry || err) return;
-    if (launch_dora_prep(dtype, dora_sites_dev, dora_sites.data(), (int)dora_sites.size(), down, up, m, stream) != 0) {
-      err = true;
-      return;
+    const bool same = reuse && dora_ready_down == down && dora_ready_up == up && dora_ready_mult == m;
+    if (!same) {
+      if (launch_dora_prep(dtype, dora_sites_dev, dora_sites.data(), (int)dora_sites.size(), down, up, m, stream) != 0) {
+        err = true;
+        return;
+      }
+      dora_ready_down = down;
+      dora_ready_up = up;
+      dora_ready_mult = m;
+      dora_ready_t = false;
     }
-    for (size_t i = 0; i < dora_sites.size(); ++i) {
-      const DoraSite& d = dora_sites[i];
-      transpose_into(d.dW, dora_dWt[i], d.nseg * d.cs, d.K, d.nseg * d.cs, 0, false);
+    if (with_t && !dora_ready_t) {  // a no-grad pass (pre-roll) never reads the transposed copies
+      if (launch_dora_transpose(dtype, dora_sites_dev, dora_sites.data(), (int)dora_sites.size(), stream) != 0) {
+        err = true;
+        return;
+      }
+      dora_ready_t = true;
     }
   }
   // LoRA shadow operands
@@ -613,8 +629,9 @@ struct smi_engine {
       d.scale = L.scale;
       d.dW = pack_alloc((size_t)L.out * L.in * esz());
       d.cnorm = (float*)pack_alloc((size_t)L.nseg * L.in * sizeof(float));
+      d.dWt = pack_alloc((size_t)L.out * L.in * esz());
       dora_sites.push_back(d);
-      dora_dWt.push_back(pack_alloc((size_t)L.out * L.in * esz()));
+      dora_dWt.push_back(d.dWt);
       return;  // no 16-bit shadow operands: the delta is a dense second GEMM
     }
     const int rtot = L.rank * L.nseg;
@@ -1076,7 +1093,8 @@ struct smi_engine {
       g.K = Mp;
       RUNP(SMI_PROF_LORA, 2.0 * g.M * g.N * M, 0.0, launch_gemm(g, stream));
       // dW was built with lscale folded in: d(dW_unscaled) = lscale * G; the common loss scale (the minimum) divides out
-      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_dora_grads(dtype, ds, G, bw_down, bw_up, d_down, d_up, lscale / y->gmul, gscale + 2 * MAXS + 1, stream));
+      float* dscr = alloc_f32(dora_grad_scratch_floats(ds));
+      RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_dora_grads(dtype, ds, G, bw_down, bw_up, d_down, d_up, lscale / y->gmul, gscale + 2 * MAXS + 1, dscr, stream));
     }
     if (lon && !L->dora) {
       const int cs = L->out / L->nseg;
@@ -1949,7 +1967,8 @@ struct smi_engine {
     Ten* temb_act = silu(emb);
     if (!prep_sites.empty() && (dry || (lora_down && lora_up && mult != 0.f)))
       RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_prep(dtype, prep_sites_dev, (int)prep_sites.size(), lora_down, lora_up, lora_shadow, stream));
-    if (lora_down && lora_up && mult != 0.f) dora_prepare(lora_down, lora_up, mult);
+    // (a forward always rebuilds: the parameters behind the same pointers change with every optimiser step)
+    if (lora_down && lora_up && mult != 0.f) dora_prepare(lora_down, lora_up, mult, saving, false);
 
     // ---- context as a [n*L, D] tensor (borrowed)
     tens->emplace_back();
@@ -2110,7 +2129,7 @@ struct smi_engine {
     if (!prep_sites.empty() && bw_down && bw_up && bw_mult != 0.f)
       RUNP(SMI_PROF_LORA, 0.0, 0.0, launch_lora_prep(dtype, prep_sites_dev, (int)prep_sites.size(), bw_down, bw_up, lora_shadow, stream));
     if (!dora_sites.empty() && bw_down && bw_up && bw_mult != 0.f) {
-      dora_prepare(bw_down, bw_up, bw_mult);
+      dora_prepare(bw_down, bw_up, bw_mult, true, true);
       RUN(launch_scale_min(gscale, n, gscale + 2 * MAXS, stream));
     }
     mult = bw_mult;

@@ -202,6 +202,7 @@ struct DoraSite {
   const void* W;                       // frozen [nseg * cs, K], 16-bit
   int64_t off_down, off_up, off_dora;  // of segment 0; segment s at + s*r*K, + s*cs*r, + s*K
   void* dW;                            // out: [nseg * cs, K] 16-bit, = lscale * dW
+  void* dWt;                           // out (launch_dora_transpose): [K, nseg * cs], the dX GEMM's operand
   float* cnorm;                        // out: [nseg, K] column norms (detached in the backward)
   int r, nseg, K, cs;
   float scale;                         // alpha / rank
@@ -209,13 +210,19 @@ struct DoraSite {
 // per adapted forward: column norms, then the scaled delta weights (lscale = mult * site.scale folded in)
 int launch_dora_prep(int dtype, const DoraSite* sites_dev, const DoraSite* sites_host, int n_sites, const float* down,
                      const float* up, float mult, hipStream_t stream);
+// dWt = dW^T of every site in ONE launch (the backward of a saved forward needs them; 280 launches of 12 us before)
+int launch_dora_transpose(int dtype, const DoraSite* sites_dev, const DoraSite* sites_host, int n_sites,
+                          hipStream_t stream);
 // dst[c][m] = src[m][c] * (f ? f[m / rows_per_sample] : 1) for m < M, 0 for M <= m < Mp      (dst [C, Mp], 16-bit)
 int launch_transpose_scaled(int dtype, const void* src, int64_t lds, void* dst, int M, int C, int Mp, const float* f,
                             int rows_per_sample, hipStream_t stream);
 // gradients of one DoRA Linear from G = dY^T X (fp32 [nseg*cs, K]): d(dora_scale), d(down) (column-wise), d(up) (row-wise);
 // everything x alpha x *alpha_dev; accumulates (+=) into the flat gradient buffers
+// `scratch`: dora_grad_scratch_floats(site) floats (row-slice partials of the column-wise sums)
+size_t dora_grad_scratch_floats(const DoraSite& site);
 int launch_dora_grads(int dtype, const DoraSite& site, const float* G, const float* down, const float* up,
-                      float* d_down, float* d_up, float alpha, const float* alpha_dev, hipStream_t stream);
+                      float* d_down, float* d_up, float alpha, const float* alpha_dev, float* scratch,
+                      hipStream_t stream);
 // scale_buf[0..n) per-sample loss scales -> out[0] = min, out[1] = 1 / min, out[2 + j] = min / scale_j
 int launch_scale_min(const float* scale_buf, int n, float* out, hipStream_t stream);
 int wgrad_grouped_finish(std::vector<WgradJob>& jobs);

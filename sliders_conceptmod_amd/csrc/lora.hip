@@ -427,32 +427,72 @@ int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, flo
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int DORA_RMAX = 32;
+constexpr int DORA_OS = 16;  // row slices of the column-gradient reduction
 
-// grid (ceil(K / 64), nseg, n_sites); 4 waves split the rows of a segment, lane = column; fixed-order LDS combine
-template <typename T>
+// grid (ceil(K / 256), nseg, n_sites); a lane owns FOUR adjacent columns (8-byte loads: a wave reads 512 contiguous bytes
+// of a row instead of 128), the 4 waves split the rows of a segment; fixed-order LDS combine
+template <typename T, int RC>  // RC: rank class (>= every site's rank): rank loops unroll, arrays stay in registers
 __global__ __launch_bounds__(256) void dora_norm_kernel(const DoraSite* __restrict__ sites, const float* __restrict__ down,
                                                         const float* __restrict__ up) {
-  __shared__ float red[4][64];
+  __shared__ float red[4][4][64];
   const DoraSite st = sites[blockIdx.z];
   const int sgm = blockIdx.y;
-  if (sgm >= st.nseg) return;
+  if (sgm >= st.nseg || (int)blockIdx.x * 256 >= st.K) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
-  float acc = 0.f;
-  if (k < st.K) {
-    float a[DORA_RMAX];
-    for (int q = 0; q < st.r; ++q) a[q] = down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+  const int k = blockIdx.x * 256 + lane * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (k < st.K) {  // K % 8 == 0: a lane's four columns exist together
+    f32x4 a[RC];
+#pragma unroll
+    for (int q = 0; q < RC; ++q)
+      a[q] = q < st.r ? *reinterpret_cast<const f32x4*>(down + st.off_down + ((int64_t)sgm * st.r + q) * st.K + k)
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
     const T* W = reinterpret_cast<const T*>(st.W) + (int64_t)sgm * st.cs * st.K + k;
     const float* B = up + st.off_up + (int64_t)sgm * st.cs * st.r;
     for (int o = w; o < st.cs; o += 4) {
-      float v = to_f(W[(int64_t)o * st.K]);
-      for (int q = 0; q < st.r; ++q) v += B[(int64_t)o * st.r + q] * a[q];
-      acc += v * v;
+      union { u32x2 u; T e[4]; } wv;
+      wv.u = *reinterpret_cast<const u32x2*>(W + (int64_t)o * st.K);
+      float v[4] = {to_f(wv.e[0]), to_f(wv.e[1]), to_f(wv.e[2]), to_f(wv.e[3])};
+#pragma unroll
+      for (int q = 0; q < RC; ++q) {
+        if (q < st.r) {
+          const float b = B[(int64_t)o * st.r + q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b * a[q][e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += v[e] * v[e];
     }
   }
-  red[w][lane] = acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[w][e][lane] = acc[e];
   __syncthreads();
-  if (w == 0 && k < st.K) st.cnorm[(int64_t)sgm * st.K + k] = sqrtf((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (w == 0 && k < st.K) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      st.cnorm[(int64_t)sgm * st.K + k + e] =
+          sqrtf((red[0][e][lane] + red[1][e][lane]) + (red[2][e][lane] + red[3][e][lane]));
+  }
+}
+
+// every site's dWt[k][o] = dW[o][k] through a 64 x 64 LDS tile; grid (max tiles, n_sites)
+template <typename T>
+__global__ __launch_bounds__(256) void dora_transpose_kernel(const DoraSite* __restrict__ sites) {
+  __shared__ T tile[64][66];
+  const DoraSite st = sites[blockIdx.y];
+  const int R = st.nseg * st.cs, K = st.K;
+  const int tk = (K + 63) / 64, tr = (R + 63) / 64;
+  if ((int)blockIdx.x >= tk * tr) return;
+  const int r0 = ((int)blockIdx.x / tk) * 64, k0 = ((int)blockIdx.x % tk) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const T* src = reinterpret_cast<const T*>(st.dW);
+  T* dst = reinterpret_cast<T*>(st.dWt);
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < R && k0 + tx < K) tile[i][tx] = src[(int64_t)(r0 + i) * K + k0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (k0 + i < K && r0 + tx < R) dst[(int64_t)(k0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
 // grid (blocks, n_sites): dW[o][k] = lscale * ((W + up down)[o][k] * g[k] / n[k] - W[o][k]), 8 columns per thread
@@ -508,72 +548,103 @@ __global__ __launch_bounds__(256) void transpose_scaled_kernel(const T* __restri
   }
 }
 
-// column-wise gradients: grid (ceil(K / 64), nseg): d(g)[k] = a * sum_o G V / n;  d(down)[q][k] = a * (g / n) * sum_o up[o][q] G[o][k]
-template <typename T>
+// column-wise gradients: d(g)[k] = a * sum_o G V / n;  d(down)[q][k] = a * (g / n) * sum_o up[o][q] G[o][k].
+// Two stages, fixed order (no atomics): grid (ceil(K / 64), nseg, DORA_OS) -- slice z sums the rows [z cs / OS, (z + 1) cs / OS)
+// of its 64 columns into part[(sgm OS + z)(1 + r) + j][k]; the final kernel adds the slices in order and scales.  (One stage
+// with grid (K / 64, nseg) was 20-60 workgroups walking a 6.5-20 MB matrix: 236 us per site, 33 ms per SD-XL step.)
+template <typename T, int RC>
 __global__ __launch_bounds__(256) void dora_col_grad_kernel(DoraSite st, const float* __restrict__ G,
                                                             const float* __restrict__ down, const float* __restrict__ up,
-                                                            float* __restrict__ d_down, float* __restrict__ d_up, float alpha,
-                                                            const float* __restrict__ alpha_dev) {
-  __shared__ float red[4][DORA_RMAX + 1][64];
-  const int sgm = blockIdx.y;
+                                                            float* __restrict__ part) {
+  __shared__ float red[4][RC + 1][64];
+  const int sgm = blockIdx.y, os = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
-  float dg = 0.f, da[DORA_RMAX];
-  for (int q = 0; q < st.r; ++q) da[q] = 0.f;
+  const int o0 = (int)((int64_t)os * st.cs / DORA_OS), o1 = (int)((int64_t)(os + 1) * st.cs / DORA_OS);
+  float dg = 0.f, da[RC], a[RC];
+#pragma unroll
+  for (int q = 0; q < RC; ++q) da[q] = 0.f, a[q] = 0.f;
   if (k < st.K) {
-    float a[DORA_RMAX];
-    for (int q = 0; q < st.r; ++q) a[q] = down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+#pragma unroll
+    for (int q = 0; q < RC; ++q)
+      if (q < st.r) a[q] = down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
     const T* W = reinterpret_cast<const T*>(st.W) + (int64_t)sgm * st.cs * st.K + k;
     const float* B = up + st.off_up + (int64_t)sgm * st.cs * st.r;
     const float* Gs = G + (int64_t)sgm * st.cs * st.K + k;
-    for (int o = w; o < st.cs; o += 4) {
+    for (int o = o0 + w; o < o1; o += 4) {
       const float gv = Gs[(int64_t)o * st.K];
       float v = to_f(W[(int64_t)o * st.K]);
-      for (int q = 0; q < st.r; ++q) {
-        const float b = B[(int64_t)o * st.r + q];
-        v += b * a[q];
-        da[q] += b * gv;
+#pragma unroll
+      for (int q = 0; q < RC; ++q) {
+        if (q < st.r) {
+          const float b = B[(int64_t)o * st.r + q];
+          v += b * a[q];
+          da[q] += b * gv;
+        }
       }
       dg += gv * v;
     }
   }
   red[w][0][lane] = dg;
-  for (int q = 0; q < st.r; ++q) red[w][1 + q][lane] = da[q];
+#pragma unroll
+  for (int q = 0; q < RC; ++q) red[w][1 + q][lane] = da[q];
   __syncthreads();
-  if (w == 0 && k < st.K) {
-    const float al = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
-    const float n = st.cnorm[(int64_t)sgm * st.K + k];
-    const float g = up[st.off_dora + (int64_t)sgm * st.K + k];
-    const float s0 = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
-    d_up[st.off_dora + (int64_t)sgm * st.K + k] += al * s0 / n;
-    for (int q = 0; q < st.r; ++q) {
-      const float sq = (red[0][1 + q][lane] + red[1][1 + q][lane]) + (red[2][1 + q][lane] + red[3][1 + q][lane]);
-      d_down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k] += al * (g / n) * sq;
-    }
+  if (k < st.K) {
+    float* out = part + ((int64_t)sgm * DORA_OS + os) * (1 + st.r) * st.K + k;
+    for (int jx = w; jx <= st.r; jx += 4)
+      out[(int64_t)jx * st.K] = (red[0][jx][lane] + red[1][jx][lane]) + (red[2][jx][lane] + red[3][jx][lane]);
   }
 }
 
-// row-wise gradient: one wave per output row: d(up)[o][q] = a * sum_k G[o][k] (g[k] / n[k]) down[q][k]
+// grid (ceil(K / 64), nseg), 256 threads: wave w takes the quantities j = w, w + 4, ... (j = 0: d(g); j = 1 + q: d(down)[q]);
+// also leaves g / n per column behind the partials for the row-wise kernel (one division per column, not per element)
+__global__ __launch_bounds__(256) void dora_col_final_kernel(DoraSite st, float* __restrict__ part,
+                                                             const float* __restrict__ up, float* __restrict__ d_down,
+                                                             float* __restrict__ d_up, float alpha,
+                                                             const float* __restrict__ alpha_dev) {
+  const int sgm = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  if (k >= st.K) return;
+  const float al = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
+  const float n = st.cnorm[(int64_t)sgm * st.K + k];
+  const float g = up[st.off_dora + (int64_t)sgm * st.K + k];
+  if (w == 0) part[(int64_t)st.nseg * DORA_OS * (1 + st.r) * st.K + (int64_t)sgm * st.K + k] = g / n;
+  for (int jx = w; jx <= st.r; jx += 4) {
+    float s = 0.f;
+    for (int os = 0; os < DORA_OS; ++os) s += part[(((int64_t)sgm * DORA_OS + os) * (1 + st.r) + jx) * st.K + k];
+    if (jx == 0) d_up[st.off_dora + (int64_t)sgm * st.K + k] += al * s / n;
+    else d_down[st.off_down + ((int64_t)sgm * st.r + (jx - 1)) * st.K + k] += al * (g / n) * s;
+  }
+}
+
+// row-wise gradient: one wave per output row: d(up)[o][q] = a * sum_k G[o][k] (g[k] / n[k]) down[q][k]; gn = g / n per column
+template <int RC>
 __global__ __launch_bounds__(256) void dora_row_grad_kernel(DoraSite st, const float* __restrict__ G,
-                                                            const float* __restrict__ down, const float* __restrict__ up,
+                                                            const float* __restrict__ down, const float* __restrict__ gn_all,
                                                             float* __restrict__ d_up, float alpha,
                                                             const float* __restrict__ alpha_dev) {
   const int lane = threadIdx.x & 63;
   const int64_t ot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ot >= (int64_t)st.nseg * st.cs) return;
   const int sgm = (int)(ot / st.cs);
-  float acc[DORA_RMAX];
-  for (int q = 0; q < st.r; ++q) acc[q] = 0.f;
-  const float* g = up + st.off_dora + (int64_t)sgm * st.K;
-  const float* n = st.cnorm + (int64_t)sgm * st.K;
+  float acc[RC];
+#pragma unroll
+  for (int q = 0; q < RC; ++q) acc[q] = 0.f;
+  const float* gn = gn_all + (int64_t)sgm * st.K;
   for (int k = lane; k < st.K; k += 64) {
-    const float t = G[ot * st.K + k] * (g[k] / n[k]);
-    for (int q = 0; q < st.r; ++q) acc[q] += t * down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+    const float t = G[ot * st.K + k] * gn[k];
+#pragma unroll
+    for (int q = 0; q < RC; ++q)
+      if (q < st.r) acc[q] += t * down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
   }
   const float al = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
-  for (int q = 0; q < st.r; ++q) {
-    const float sum = wave_sum(acc[q]);
-    if (lane == 0) d_up[st.off_up + ot * st.r + q] += al * sum;
+#pragma unroll
+  for (int q = 0; q < RC; ++q) {
+    if (q < st.r) {
+      const float sum = wave_sum(acc[q]);
+      if (lane == 0) d_up[st.off_up + ot * st.r + q] += al * sum;
+    }
   }
 }
 
@@ -598,14 +669,38 @@ int launch_dora_prep(int dtype, const DoraSite* sites_dev, const DoraSite* sites
     kmax = std::max(kmax, sites_host[i].K);
     segmax = std::max(segmax, sites_host[i].nseg);
   }
-  dim3 gn(cdiv(kmax, 64), segmax, n_sites), gd(128, n_sites);
+  dim3 gn(cdiv(kmax, 256), segmax, n_sites), gd(128, n_sites);
+  int rmax = 1;
+  for (int i = 0; i < n_sites; ++i) rmax = std::max(rmax, sites_host[i].r);
+#define NORM(TT_, RC_) hipLaunchKernelGGL((dora_norm_kernel<TT_, RC_>), gn, dim3(256), 0, stream, sites_dev, down, up)
+#define NORMS(TT_)                                                                         \
+  do {                                                                                     \
+    if (rmax <= 4) NORM(TT_, 4); else if (rmax <= 8) NORM(TT_, 8);                         \
+    else if (rmax <= 16) NORM(TT_, 16); else NORM(TT_, 32);                                \
+  } while (0)
   if (dtype == DT_F16) {
-    hipLaunchKernelGGL(dora_norm_kernel<f16>, gn, dim3(256), 0, stream, sites_dev, down, up);
+    NORMS(f16);
     hipLaunchKernelGGL(dora_delta_kernel<f16>, gd, dim3(256), 0, stream, sites_dev, down, up, mult);
   } else {
-    hipLaunchKernelGGL(dora_norm_kernel<bf16>, gn, dim3(256), 0, stream, sites_dev, down, up);
+    NORMS(bf16);
     hipLaunchKernelGGL(dora_delta_kernel<bf16>, gd, dim3(256), 0, stream, sites_dev, down, up, mult);
   }
+#undef NORMS
+#undef NORM
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_dora_transpose(int dtype, const DoraSite* sites_dev, const DoraSite* sites_host, int n_sites,
+                          hipStream_t stream) {
+  if (n_sites <= 0) return 0;
+  int tmax = 1;
+  for (int i = 0; i < n_sites; ++i)
+    tmax = std::max(tmax, cdiv(sites_host[i].K, 64) * cdiv(sites_host[i].nseg * sites_host[i].cs, 64));
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(dora_transpose_kernel<f16>, dim3(tmax, n_sites), dim3(256), 0, stream, sites_dev);
+  else
+    hipLaunchKernelGGL(dora_transpose_kernel<bf16>, dim3(tmax, n_sites), dim3(256), 0, stream, sites_dev);
   SMI_HIP(hipGetLastError());
   return 0;
 }
@@ -621,15 +716,34 @@ int launch_transpose_scaled(int dtype, const void* src, int64_t lds, void* dst, 
   return 0;
 }
 
+size_t dora_grad_scratch_floats(const DoraSite& site) {  // row-slice partials + g / n per column
+  return (size_t)site.nseg * DORA_OS * (1 + site.r) * site.K + (size_t)site.nseg * site.K;
+}
+
 int launch_dora_grads(int dtype, const DoraSite& site, const float* G, const float* down, const float* up,
-                      float* d_down, float* d_up, float alpha, const float* alpha_dev, hipStream_t stream) {
-  dim3 gc(cdiv(site.K, 64), site.nseg);
-  if (dtype == DT_F16)
-    hipLaunchKernelGGL(dora_col_grad_kernel<f16>, gc, dim3(256), 0, stream, site, G, down, up, d_down, d_up, alpha, alpha_dev);
-  else
-    hipLaunchKernelGGL(dora_col_grad_kernel<bf16>, gc, dim3(256), 0, stream, site, G, down, up, d_down, d_up, alpha, alpha_dev);
-  hipLaunchKernelGGL(dora_row_grad_kernel, dim3(cdiv(site.nseg * site.cs, 4)), dim3(256), 0, stream, site, G, down, up,
-                     d_up, alpha, alpha_dev);
+                      float* d_down, float* d_up, float alpha, const float* alpha_dev, float* scratch,
+                      hipStream_t stream) {
+  SMI_CHECK(site.r >= 1 && site.r <= DORA_RMAX, "dora: rank %d", site.r);
+  dim3 gc(cdiv(site.K, 64), site.nseg, DORA_OS);
+  const float* gn = scratch + (size_t)site.nseg * DORA_OS * (1 + site.r) * site.K;
+  const dim3 gr(cdiv(site.nseg * site.cs, 4));
+#define COL(TT_, RC_) hipLaunchKernelGGL((dora_col_grad_kernel<TT_, RC_>), gc, dim3(256), 0, stream, site, G, down, up, scratch)
+#define ROW(RC_) hipLaunchKernelGGL((dora_row_grad_kernel<RC_>), gr, dim3(256), 0, stream, site, G, down, gn, d_up, alpha, alpha_dev)
+#define BYRANK(X_)                                                                               \
+  do {                                                                                           \
+    if (site.r <= 4) { X_(4); } else if (site.r <= 8) { X_(8); } else if (site.r <= 16) { X_(16); } else { X_(32); } \
+  } while (0)
+#define COLF16(RC_) COL(f16, RC_)
+#define COLBF16(RC_) COL(bf16, RC_)
+  if (dtype == DT_F16) BYRANK(COLF16); else BYRANK(COLBF16);
+  hipLaunchKernelGGL(dora_col_final_kernel, dim3(cdiv(site.K, 64), site.nseg), dim3(256), 0, stream, site, scratch, up,
+                     d_down, d_up, alpha, alpha_dev);
+  BYRANK(ROW);
+#undef COLF16
+#undef COLBF16
+#undef BYRANK
+#undef ROW
+#undef COL
   SMI_HIP(hipGetLastError());
   return 0;
 }
