@@ -427,7 +427,7 @@ int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, flo
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int DORA_RMAX = 32;
-constexpr int DORA_OS = 16;  // row slices of the column-gradient reduction
+constexpr int DORA_OS = 64;  // row slices of the column-gradient reduction
 
 // grid (ceil(K / 256), nseg, n_sites); a lane owns FOUR adjacent columns (8-byte loads: a wave reads 512 contiguous bytes
 // of a row instead of 128), the 4 waves split the rows of a segment; fixed-order LDS combine
@@ -548,32 +548,70 @@ __global__ __launch_bounds__(256) void transpose_scaled_kernel(const T* __restri
   }
 }
 
+// the same with 16-byte accesses on both sides (C % 8 == 0, lds % 8 == 0, 16-byte aligned src; Mp % 64 == 0 always)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_scaled_vec_kernel(const T* __restrict__ src, int64_t lds, T* __restrict__ dst,
+                                                                   int M, int C, int Mp, const float* __restrict__ f, int rps) {
+  __shared__ float tile[64][65];
+  const int tilesC = (C + 63) / 64;
+  const int tm = (blockIdx.x / tilesC) * 64, tc = (blockIdx.x % tilesC) * 64;
+  for (int v = threadIdx.x; v < 512; v += 256) {
+    const int i = v >> 3, c0 = (v & 7) * 8;
+    const int m = tm + i, c = tc + c0;
+    Pack8<T> t;
+    t.u = u32x4{0u, 0u, 0u, 0u};
+    float sc = 0.f;
+    if (m < M && c < C) {
+      t.u = *reinterpret_cast<const u32x4*>(src + (int64_t)m * lds + c);
+      sc = f ? f[m / rps] : 1.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[i][c0 + e] = to_f(t.e[e]) * sc;
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < 512; v += 256) {
+    const int ci = v >> 3, m0 = (v & 7) * 8;
+    const int c = tc + ci, m = tm + m0;
+    if (c < C && m < Mp) {
+      Pack8<T> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(tile[m0 + e][ci]);
+      *reinterpret_cast<u32x4*>(dst + (int64_t)c * Mp + m) = o.u;
+    }
+  }
+}
+
 // column-wise gradients: d(g)[k] = a * sum_o G V / n;  d(down)[q][k] = a * (g / n) * sum_o up[o][q] G[o][k].
-// Two stages, fixed order (no atomics): grid (ceil(K / 64), nseg, DORA_OS) -- slice z sums the rows [z cs / OS, (z + 1) cs / OS)
-// of its 64 columns into part[(sgm OS + z)(1 + r) + j][k]; the final kernel adds the slices in order and scales.  (One stage
+// Two stages, fixed order (no atomics): grid (ceil(K / 256), nseg, DORA_OS) -- slice z sums the rows [z cs / OS, (z + 1) cs / OS)
+// of its 256 columns into part[(sgm OS + z)(1 + r) + j][k]; the final kernel adds the slices in order and scales.  (One stage
 // with grid (K / 64, nseg) was 20-60 workgroups walking a 6.5-20 MB matrix: 236 us per site, 33 ms per SD-XL step.)
 template <typename T, int RC>
 __global__ __launch_bounds__(256) void dora_col_grad_kernel(DoraSite st, const float* __restrict__ G,
                                                             const float* __restrict__ down, const float* __restrict__ up,
                                                             float* __restrict__ part) {
-  __shared__ float red[4][RC + 1][64];
+  // grid (ceil(K / 256), nseg, DORA_OS): a lane owns four adjacent columns (16-byte loads of G, 8-byte loads of W)
+  __shared__ f32x4 red[4][64];
   const int sgm = blockIdx.y, os = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
+  const int k = blockIdx.x * 256 + lane * 4;
+  const bool ok = k < st.K;  // K % 8 == 0: a lane's four columns exist together
   const int o0 = (int)((int64_t)os * st.cs / DORA_OS), o1 = (int)((int64_t)(os + 1) * st.cs / DORA_OS);
-  float dg = 0.f, da[RC], a[RC];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dg = zero, da[RC], a[RC];
 #pragma unroll
-  for (int q = 0; q < RC; ++q) da[q] = 0.f, a[q] = 0.f;
-  if (k < st.K) {
+  for (int q = 0; q < RC; ++q) da[q] = zero, a[q] = zero;
+  if (ok) {
 #pragma unroll
     for (int q = 0; q < RC; ++q)
-      if (q < st.r) a[q] = down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+      if (q < st.r) a[q] = *reinterpret_cast<const f32x4*>(down + st.off_down + ((int64_t)sgm * st.r + q) * st.K + k);
     const T* W = reinterpret_cast<const T*>(st.W) + (int64_t)sgm * st.cs * st.K + k;
     const float* B = up + st.off_up + (int64_t)sgm * st.cs * st.r;
     const float* Gs = G + (int64_t)sgm * st.cs * st.K + k;
     for (int o = o0 + w; o < o1; o += 4) {
-      const float gv = Gs[(int64_t)o * st.K];
-      float v = to_f(W[(int64_t)o * st.K]);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + (int64_t)o * st.K);
+      union { u32x2 u; T e[4]; } wv;
+      wv.u = *reinterpret_cast<const u32x2*>(W + (int64_t)o * st.K);
+      f32x4 v = {to_f(wv.e[0]), to_f(wv.e[1]), to_f(wv.e[2]), to_f(wv.e[3])};
 #pragma unroll
       for (int q = 0; q < RC; ++q) {
         if (q < st.r) {
@@ -585,14 +623,17 @@ __global__ __launch_bounds__(256) void dora_col_grad_kernel(DoraSite st, const f
       dg += gv * v;
     }
   }
-  red[w][0][lane] = dg;
+  // the four waves' sums, one quantity at a time (fixed order); wave jx & 3 writes quantity jx
+  float* out = part + ((int64_t)sgm * DORA_OS + os) * (1 + st.r) * st.K + k;
 #pragma unroll
-  for (int q = 0; q < RC; ++q) red[w][1 + q][lane] = da[q];
-  __syncthreads();
-  if (k < st.K) {
-    float* out = part + ((int64_t)sgm * DORA_OS + os) * (1 + st.r) * st.K + k;
-    for (int jx = w; jx <= st.r; jx += 4)
-      out[(int64_t)jx * st.K] = (red[0][jx][lane] + red[1][jx][lane]) + (red[2][jx][lane] + red[3][jx][lane]);
+  for (int jx = 0; jx <= RC; ++jx) {
+    if (jx <= st.r) {  // block-uniform
+      red[w][lane] = jx == 0 ? dg : da[jx > 0 ? jx - 1 : 0];
+      __syncthreads();
+      if (w == (jx & 3) && ok)
+        *reinterpret_cast<f32x4*>(out + (int64_t)jx * st.K) = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      __syncthreads();
+    }
   }
 }
 
@@ -618,7 +659,8 @@ __global__ __launch_bounds__(256) void dora_col_final_kernel(DoraSite st, float*
   }
 }
 
-// row-wise gradient: one wave per output row: d(up)[o][q] = a * sum_k G[o][k] (g[k] / n[k]) down[q][k]; gn = g / n per column
+// row-wise gradient: one wave per output row: d(up)[o][q] = a * sum_k G[o][k] (g[k] / n[k]) down[q][k]; gn = g / n per column.
+// A lane takes four adjacent columns per step (16-byte loads; K % 8 == 0): 5 steps for K = 1280 instead of 20.
 template <int RC>
 __global__ __launch_bounds__(256) void dora_row_grad_kernel(DoraSite st, const float* __restrict__ G,
                                                             const float* __restrict__ down, const float* __restrict__ gn_all,
@@ -632,11 +674,19 @@ __global__ __launch_bounds__(256) void dora_row_grad_kernel(DoraSite st, const f
 #pragma unroll
   for (int q = 0; q < RC; ++q) acc[q] = 0.f;
   const float* gn = gn_all + (int64_t)sgm * st.K;
-  for (int k = lane; k < st.K; k += 64) {
-    const float t = G[ot * st.K + k] * gn[k];
+  const float* Gr = G + ot * st.K;
+  const float* dn = down + st.off_down + (int64_t)sgm * st.r * st.K;
+  for (int k = lane * 4; k < st.K; k += 256) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(Gr + k);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(gn + k);
+    const f32x4 t = gv * rv;
 #pragma unroll
-    for (int q = 0; q < RC; ++q)
-      if (q < st.r) acc[q] += t * down[st.off_down + ((int64_t)sgm * st.r + q) * st.K + k];
+    for (int q = 0; q < RC; ++q) {
+      if (q < st.r) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dn + (int64_t)q * st.K + k);
+        acc[q] += (t[0] * d[0] + t[1] * d[1]) + (t[2] * d[2] + t[3] * d[3]);
+      }
+    }
   }
   const float al = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
 #pragma unroll
@@ -708,6 +758,15 @@ int launch_dora_transpose(int dtype, const DoraSite* sites_dev, const DoraSite* 
 int launch_transpose_scaled(int dtype, const void* src, int64_t lds, void* dst, int M, int C, int Mp, const float* f,
                             int rows_per_sample, hipStream_t stream) {
   const int grid = cdiv(Mp, 64) * cdiv(C, 64);
+  if (C % 8 == 0 && lds % 8 == 0 && Mp % 64 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    if (dtype == DT_F16)
+      hipLaunchKernelGGL(transpose_scaled_vec_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, lds, (f16*)dst, M, C, Mp, f, rows_per_sample);
+    else
+      hipLaunchKernelGGL(transpose_scaled_vec_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)src, lds, (bf16*)dst, M, C, Mp, f, rows_per_sample);
+    SMI_HIP(hipGetLastError());
+    return 0;
+  }
   if (dtype == DT_F16)
     hipLaunchKernelGGL(transpose_scaled_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)src, lds, (f16*)dst, M, C, Mp, f, rows_per_sample);
   else
@@ -724,7 +783,7 @@ int launch_dora_grads(int dtype, const DoraSite& site, const float* G, const flo
                       float* d_down, float* d_up, float alpha, const float* alpha_dev, float* scratch,
                       hipStream_t stream) {
   SMI_CHECK(site.r >= 1 && site.r <= DORA_RMAX, "dora: rank %d", site.r);
-  dim3 gc(cdiv(site.K, 64), site.nseg, DORA_OS);
+  dim3 gc(cdiv(site.K, 256), site.nseg, DORA_OS);
   const float* gn = scratch + (size_t)site.nseg * DORA_OS * (1 + site.r) * site.K;
   const dim3 gr(cdiv(site.nseg * site.cs, 4));
 #define COL(TT_, RC_) hipLaunchKernelGGL((dora_col_grad_kernel<TT_, RC_>), gc, dim3(256), 0, stream, site, G, down, up, scratch)
