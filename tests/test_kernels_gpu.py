@@ -294,7 +294,9 @@ def test_groupnorm_forward_backward(lib, dt, nb, HW, Cc, G, silu):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,Cc", [(1000, 320), (4096, 1280), (77, 640), (5, 64)])
+@pytest.mark.parametrize("M,Cc", [(1000, 320), (4096, 1280), (77, 640), (5, 64),
+                                  # two rows per wave (M >= 16384) with an odd tail row; 4 and 2 vectors per lane (CLIP widths)
+                                  (16384 + 3, 640), (16390, 1280), (300, 2048), (231, 768), (154, 1024)])
 def test_layernorm_forward_backward(lib, dt, M, Cc):
     x = rnd(M, Cc, dt=dt, seed=1) * 1.5 - 0.3
     gamma, beta = (1 + 0.1 * rnd(Cc, dt=dt, seed=2)).to(dt), rnd(Cc, dt=dt, scale=0.1, seed=3)
