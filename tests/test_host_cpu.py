@@ -362,3 +362,22 @@ def test_dora_network_names_shapes_and_key_order_match_reference(goldens, model,
     net2 = D.DoRANetwork(unet, rank=4, target_replace=["Attention"], train_method=method)
     net2.load_state_dict(sd)
     torch.testing.assert_close(net2.flat.detach(), net.flat.detach())
+
+
+def test_posterior_rows_sample_like_separate_posteriors():
+    """vae.DiagonalGaussianDistribution.rows (train_util.get_noisy_image_pair): the posterior of samples [lo, hi) of a batched
+    encode equals the posterior built from those samples' moments alone, and sampling the rows one after the other from a
+    generator seeded per row reproduces the one-call-per-image draws of the reference loop (I/train_lora-scale-xl.py:220-247)."""
+    import torch
+    from sliders_conceptmod_amd.vae import DiagonalGaussianDistribution as D
+    g = torch.Generator().manual_seed(0)
+    moments = torch.randn(3, 8, 4, 4, generator=g)
+    moments[:, 4:] = moments[:, 4:] * 20  # exercises the clamp to [-30, 20]
+    whole = D(moments)
+    for i in range(3):
+        part, alone = whole.rows(i, i + 1), D(moments[i:i + 1])
+        assert torch.equal(part.mean, alone.mean) and torch.equal(part.logvar, alone.logvar) and torch.equal(part.std, alone.std)
+        a = part.sample(torch.Generator().manual_seed(7))
+        b = alone.sample(torch.Generator().manual_seed(7))
+        assert torch.equal(a, b) and a.shape == (1, 4, 4, 4)
+    assert torch.equal(whole.rows(0, 3).mode(), whole.mode())
