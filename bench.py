@@ -538,7 +538,7 @@ def main():
         elapsed = max(float(x.item()) for x in tl)  # MAX over ranks
         # the step's one collective on its own: HIP events around the flat fp32 LoRA-gradient all-reduce
         from sliders_conceptmod_amd import parallel
-        buf = step.grad.clone()
+        buf = step.msg.clone()  # [gradient | loss scalar]: the step's one message
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         parallel.allreduce_mean_(buf)
         torch.cuda.synchronize()
@@ -609,8 +609,8 @@ def main():
             "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             "rccl_world_size": seen_world, "rank_devices": rank_devices,
             "allreduce": None if allreduce_us is None else {
-                "us": allreduce_us, "bytes": int(step.grad.numel() * 4),
-                "what": "flat fp32 LoRA gradient, all-reduce(sum) + divide, on the compute stream (RCCL), issued after "
+                "us": allreduce_us, "bytes": int(step.msg.numel() * 4),
+                "what": "flat fp32 LoRA gradient + the loss scalar in ONE message, all-reduce(sum) + divide, on the compute stream (RCCL), issued after "
                         "the deferred grouped weight-gradient launches of the backward: nothing overlaps it (it is "
                         "~0.1 % of a step)"},
             "loss": loss_val,

@@ -462,9 +462,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const float sl = p.scale * LOG2E;
   // Row constants as the INITIAL ACCUMULATORS of the two score products (the query is on the lane, so they are
   // lane constants): S' = K Q^T - lse / scale leaves its MFMA chain ready for p = exp2(sl * S'), dP' = V dO^T - delta
-  // is the factor of dS -- no zero fill, no subtraction, and no key mask either: rows of K / V past Nk are staged as
-  // zeros, so whatever finite dS they get multiplies a zero row of K.  Padded queries (their Q / dO fragments are
-  // zero) keep both constants at 0.
+  // is the factor of dS -- no zero fill, no subtraction.  Rows of K / V past Nk are staged as zeros; their dS is
+  // zeroed in the ragged last tile (below).  Padded queries (their Q / dO fragments are zero) keep both constants at 0.
   const float cl = qok ? -p.lse[stat] / p.scale : 0.f, cd = qok ? -dlt : 0.f;
   f32x16 c_lse, c_dlt;
 #pragma unroll
@@ -517,6 +516,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * sl) * dp[r];  // dS^T = P^T o (dP^T - delta)
+      // keys past Nk (ragged last tile only, wave-uniform test): their K / V rows are staged as zeros, so p = exp(-lse)
+      // and dS = -p delta -- with a strongly negative log-sum-exp and a loss-scaled delta that leaves the fp16 range,
+      // and inf x (the zero K row) = NaN would enter dQ.  dS of a key that does not exist is 0.
+      if (k0 + TK > p.Nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + sub * 32 + acc_row(r, h2) >= p.Nk) st[r] = 0.f;
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const auto df = pack8<T>(st, s2);
@@ -705,6 +712,427 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
+// =============================================================================================================
+// Short key sequences (Nk <= 96: cross-attention on the 77 text tokens, T/train_lora.py:68 routes attn2 through the same
+// fused attention).  The generic kernels above run these as two 64-key tiles of an online softmax -- 40 % padding, a
+// barrier and a K / V staging round trip per tile, Q / O moved in 16-32-byte pieces per row -- at 171 TF/s, twice their
+// HBM time (Q read + O write).  Here ALL keys of a head sit in LDS, staged once per workgroup: three 32-key sub-tiles,
+// one-pass softmax (no running maximum, no rescale), and Q / dO / O / dQ tiles move in whole 16-byte chunks of contiguous rows
+// through a per-wave LDS tile (8 lanes per 128-byte row) -- the kernel is HBM-bound by construction.
+// A workgroup = 4 waves x 32 queries; a wave stages, reads and writes only ITS 32 rows of the tile, so the only
+// workgroup barrier is the one after K / V.
+// =============================================================================================================
+constexpr int XS_KEYS = 96;  // 3 sub-tiles of 32 keys
+
+// orders a wave's own LDS accesses (ds operations of one wave execute in order; this only stops the compiler from moving
+// a read above a write of another lane to the same tile)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int DP>
+struct XsTile {
+  static constexpr int LDN = DP + 8;
+  static constexpr int CPR = DP / 8;     // 16-byte chunks per row
+  static constexpr int TOT = 32 * CPR;   // chunks of a wave's 32-row tile, dealt to the lanes in row-major order
+  static constexpr int NIT = TOT / 64;   // (DP = 64: 4 instructions of 8 rows x 128 B)
+  static_assert(TOT % 64 == 0, "tile depth");
+  // this lane's chunk i of the wave's 32-row tile: (row, first column)
+  static __device__ __forceinline__ void rc(int lane, int i, int& row, int& col) {
+    const int idx = lane + 64 * i;
+    row = idx / CPR;
+    col = (idx - row * CPR) * 8;
+  }
+  static __device__ __forceinline__ void load(u32x4 (&reg)[NIT], __amdgpu_buffer_rsrc_t r, int64_t row0, int nrows,
+                                              int64_t ld, int col0, int D, int lane) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      int row, col;
+      rc(lane, i, row, col);
+      const bool ok = (row0 + row < nrows) && (col < D);
+      reg[i] = buf_load16(r, ok ? (uint32_t)(((row0 + row) * ld + col0 + col) * 2) : OOB);
+    }
+  }
+  static __device__ __forceinline__ void to_lds(const u32x4 (&reg)[NIT], T* tile, int lane) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      int row, col;
+      rc(lane, i, row, col);
+      *reinterpret_cast<u32x4*>(tile + row * LDN + col) = reg[i];
+    }
+  }
+  // rows of the wave's tile back out as whole 16-byte chunks (rows >= nrows and columns >= D are dropped)
+  static __device__ __forceinline__ void store_rows(const T* tile, __amdgpu_buffer_rsrc_t r, int64_t row0, int nrows,
+                                                    int64_t ld, int col0, int D, int lane) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      int row, col;
+      rc(lane, i, row, col);
+      const bool ok = (row0 + row < nrows) && (col < D);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * LDN + col);
+      buf_store16(r, ok ? (uint32_t)(((row0 + row) * ld + col0 + col) * 2) : OOB, v);
+    }
+  }
+};
+
+// K (row reads), optionally K again at the transposed-read stride, V (row reads or transposed reads): all 96 rows, zeros
+// past Nk / D.  Every thread of the workgroup takes part; the caller barriers.
+template <typename T, int DP>
+__device__ __forceinline__ void xs_stage_kv(__amdgpu_buffer_rsrc_t rK, __amdgpu_buffer_rsrc_t rV, int Nk, int64_t ldk,
+                                            int64_t ldv, int col0, int D, int tid, T* Kn, T* Ktr, T* Vn, T* Vtr) {
+  constexpr int CPR = DP / 8, LDN = DP + 8, LDV = tr_stride(DP);
+  constexpr int TOT = XS_KEYS * CPR, NITK = (TOT + 255) / 256;
+  u32x4 rk[NITK], rv[NITK];
+#pragma unroll
+  for (int i = 0; i < NITK; ++i) {
+    const int idx = tid + 256 * i;
+    const int row = idx / CPR, ch = idx - row * CPR;
+    const bool ok = (idx < TOT) && (row < Nk) && (ch * 8 < D);
+    rk[i] = buf_load16(rK, ok ? (uint32_t)(((int64_t)row * ldk + col0 + ch * 8) * 2) : OOB);
+    rv[i] = buf_load16(rV, ok ? (uint32_t)(((int64_t)row * ldv + col0 + ch * 8) * 2) : OOB);
+  }
+#pragma unroll
+  for (int i = 0; i < NITK; ++i) {
+    const int idx = tid + 256 * i;
+    const int row = idx / CPR, ch = idx - row * CPR;
+    if (idx < TOT) {
+      if (Kn) *reinterpret_cast<u32x4*>(Kn + row * LDN + ch * 8) = rk[i];
+      if (Ktr) *reinterpret_cast<u32x4*>(Ktr + row * LDV + ch * 8) = rk[i];
+      if (Vn) *reinterpret_cast<u32x4*>(Vn + row * LDN + ch * 8) = rv[i];
+      if (Vtr) *reinterpret_cast<u32x4*>(Vtr + row * LDV + ch * 8) = rv[i];
+    }
+  }
+}
+
+template <typename T, int DP>
+constexpr size_t xs_fwd_smem() {
+  return (size_t)(XS_KEYS * (DP + 8) + XS_KEYS * tr_stride(DP) + 128 * (DP + 8)) * sizeof(T);
+}
+template <typename T, int DP>
+constexpr size_t xs_dq_smem() {
+  return (size_t)(2 * XS_KEYS * (DP + 8) + XS_KEYS * tr_stride(DP) + 128 * (DP + 8)) * sizeof(T);
+}
+
+// forward.  grid = (query blocks per workgroup chain, H, B): workgroup x walks the 128-query blocks x, x + gridDim.x, ...
+// of its (batch, head) with K / V staged once.
+template <typename T, int DP, int NSD>
+__global__ __launch_bounds__(256, DP <= 64 ? 3 : 1) void attn_xs_fwd_kernel(AttnParams p) {
+  using X = XsTile<T, DP>;
+  constexpr int NB = DP / 32, LDN = DP + 8, LDV = tr_stride(DP);
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  T* Ks = reinterpret_cast<T*>(dyn_smem);
+  T* Vs = Ks + XS_KEYS * LDN;
+  T* Ts = Vs + XS_KEYS * LDV;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, h2 = lane >> 5;
+  int bx, head, b;
+  xcd_block(bx, head, b);
+  const int col0 = head * p.D;
+  T* tile = Ts + wave * 32 * LDN;
+
+  const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
+  const auto rO = make_rsrc((const T*)p.O + (int64_t)b * p.Nq * p.ldo, (uint32_t)((int64_t)p.Nq * p.ldo * 2));
+  const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
+  const auto rV = make_rsrc((const T*)p.V + (int64_t)b * p.Nk * p.ldv, (uint32_t)((int64_t)p.Nk * p.ldv * 2));
+
+  const int nqb = (p.Nq + 127) / 128;
+  u32x4 rq[X::NIT];
+  X::load(rq, rQ, (int64_t)bx * 128 + wave * 32, p.Nq, p.ldq, col0, p.D, lane);  // in flight under the K / V staging
+  xs_stage_kv<T, DP>(rK, rV, p.Nk, p.ldk, p.ldv, col0, p.D, tid, Ks, nullptr, nullptr, Vs);
+  __syncthreads();
+  const float sl = p.scale * LOG2E;
+
+  for (int qb = bx; qb < nqb; qb += gridDim.x) {
+    const int q0 = qb * 128 + wave * 32;
+    const int q_idx = q0 + ql;
+    X::to_lds(rq, tile, lane);
+    wave_lds_sync();
+    typename TT<T>::v8 qf[NSD];
+#pragma unroll
+    for (int s = 0; s < NSD; ++s) qf[s] = ld_frag_nat<T>(tile, LDN, ql, 16 * s + 8 * h2);
+    if (qb + (int)gridDim.x < nqb)  // the next block's rows, in flight under this block's arithmetic
+      X::load(rq, rQ, (int64_t)(qb + gridDim.x) * 128 + wave * 32, p.Nq, p.ldq, col0, p.D, lane);
+
+    // S^T[key, q] = K Q^T, all keys
+    f32x16 st[3];
+#pragma unroll
+    for (int sub = 0; sub < 3; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSD; ++s) {
+        const auto kf = ld_frag_nat<T>(Ks, LDN, sub * 32 + ql, 16 * s + 8 * h2);
+        st[sub] = TT<T>::mfma32(kf, qf[s], st[sub]);
+      }
+    }
+    // keys past Nk: only the sub-tiles that contain some (wave-uniform tests; one compare against a lane constant and one
+    // select per register -- written branch-free over all 48 registers this cost more than the exponentials)
+#pragma unroll
+    for (int sub = 0; sub < 3; ++sub) {
+      if (sub * 32 + 32 > p.Nk) {
+        asm volatile("" ::: "memory");  // keeps the (scalar) branch: hipcc otherwise if-converts all three blocks into selects
+        const int lim = p.Nk - sub * 32 - 4 * h2;  // register r holds key sub * 32 + 4 h2 + (r & 3) + 8 (r >> 2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[sub][r] = ((r & 3) + 8 * (r >> 2) >= lim) ? -INFINITY : st[sub][r];
+      }
+    }
+    if (p.causal) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int sub = 0; sub < 3; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (sub * 32 + acc_row(r, h2) > q_idx) st[sub][r] = -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 3; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, st[sub][r]);
+    m = halves_max(m);  // key 0 is visible to every query (also under the causal mask): finite
+    const float mb = m * sl;
+    // keys 80..95 (registers 8..15 of the third sub-tile) do not exist for the 77 text tokens: their exponentials, their
+    // P.V step and their row sums are skipped (wave-uniform)
+    const bool tail16 = p.Nk > 80;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[sub][r] = __builtin_amdgcn_exp2f(st[sub][r] * sl - mb);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) st[2][r] = __builtin_amdgcn_exp2f(st[2][r] * sl - mb);
+    if (tail16) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 8; r < 16; ++r) st[2][r] = __builtin_amdgcn_exp2f(st[2][r] * sl - mb);
+    }
+
+    // O^T[d, q] = V^T[d, keys] P^T[keys, q]
+    f32x16 o[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
+    auto pv_step = [&](int sub, int s2) {
+      const auto pf = pack8<T>(st[sub], s2);
+      const int kb = sub * 32 + s2 * 16 + 4 * h2;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const auto vf = ld_frag_trhw<T>(Vs, LDV, kb, i * 32, lane);
+        o[i] = TT<T>::mfma32(vf, pf, o[i]);
+      }
+      l4 = Sum4<T>::add8(pf, l4);
+    };
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      pv_step(sub, 0);
+      pv_step(sub, 1);
+    }
+    pv_step(2, 0);
+    if (tail16) {
+      asm volatile("" ::: "memory");
+      pv_step(2, 1);
+    }
+    const float l_tot = halves_sum(l4[0]);
+    const float inv = 1.f / l_tot;
+    // O rows through the wave's tile (its Q rows are consumed): a lane holds 4 consecutive d of ITS query per quad
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Pack4<T> t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t.e[j] = from_f<T>(o[i][4 * g + j] * inv);
+        *reinterpret_cast<u32x2*>(tile + ql * LDN + i * 32 + 8 * g + 4 * h2) = t.u;
+      }
+    wave_lds_sync();
+    X::store_rows(tile, rO, q0, p.Nq, p.ldo, col0, p.D, lane);
+    if (p.lse && h2 == 0 && q_idx < p.Nq) p.lse[((int64_t)b * p.H + head) * p.Nq + q_idx] = m * p.scale + __logf(l_tot);
+    wave_lds_sync();  // the stores' tile reads precede the next block's Q rows
+  }
+}
+
+// backward dQ for short key sequences: S^T, dP^T and dS^T as in attn_bwd_dq_kernel, every key at once; publishes delta.
+template <typename T, int DP, int NSD>
+__global__ __launch_bounds__(256) void attn_xs_bwd_dq_kernel(AttnParams p) {
+  using X = XsTile<T, DP>;
+  constexpr int NB = DP / 32, LDN = DP + 8, LDV = tr_stride(DP);
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  T* Ks = reinterpret_cast<T*>(dyn_smem);
+  T* Vs = Ks + XS_KEYS * LDN;
+  T* Ks2 = Vs + XS_KEYS * LDN;
+  T* Ts = Ks2 + XS_KEYS * LDV;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, h2 = lane >> 5;
+  int bx, head, b;
+  xcd_block(bx, head, b);
+  const int col0 = head * p.D;
+  T* tile = Ts + wave * 32 * LDN;
+
+  const auto rQ = make_rsrc((const T*)p.Q + (int64_t)b * p.Nq * p.ldq, (uint32_t)((int64_t)p.Nq * p.ldq * 2));
+  const auto rG = make_rsrc((const T*)p.dO + (int64_t)b * p.Nq * p.lddo, (uint32_t)((int64_t)p.Nq * p.lddo * 2));
+  const auto rO = make_rsrc((const T*)p.O + (int64_t)b * p.Nq * p.ldo, (uint32_t)((int64_t)p.Nq * p.ldo * 2));
+  const auto rD = make_rsrc((const T*)p.dQ + (int64_t)b * p.Nq * p.lddq, (uint32_t)((int64_t)p.Nq * p.lddq * 2));
+  const auto rK = make_rsrc((const T*)p.K + (int64_t)b * p.Nk * p.ldk, (uint32_t)((int64_t)p.Nk * p.ldk * 2));
+  const auto rV = make_rsrc((const T*)p.V + (int64_t)b * p.Nk * p.ldv, (uint32_t)((int64_t)p.Nk * p.ldv * 2));
+
+  const int nqb = (p.Nq + 127) / 128;
+  u32x4 rq[X::NIT], rg[X::NIT], ro[X::NIT];
+  auto fetch = [&](int qb) {
+    const int64_t r0 = (int64_t)qb * 128 + wave * 32;
+    X::load(rq, rQ, r0, p.Nq, p.ldq, col0, p.D, lane);
+    X::load(rg, rG, r0, p.Nq, p.lddo, col0, p.D, lane);
+    X::load(ro, rO, r0, p.Nq, p.ldo, col0, p.D, lane);
+  };
+  fetch(bx);
+  xs_stage_kv<T, DP>(rK, rV, p.Nk, p.ldk, p.ldv, col0, p.D, tid, Ks, Ks2, Vs, nullptr);
+  __syncthreads();
+  const float sl = p.scale * LOG2E;
+
+  for (int qb = bx; qb < nqb; qb += gridDim.x) {
+    const int q0 = qb * 128 + wave * 32;
+    const int q_idx = q0 + ql;
+    const bool qok = q_idx < p.Nq;
+    const int64_t stat = ((int64_t)b * p.H + head) * p.Nq + (qok ? q_idx : 0);
+    // Q, dO and O rows pass through the wave's tile one after the other (whole-row loads, fragment reads)
+    typename TT<T>::v8 qf[NSD], gf[NSD];
+    X::to_lds(rq, tile, lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < NSD; ++s) qf[s] = ld_frag_nat<T>(tile, LDN, ql, 16 * s + 8 * h2);
+    wave_lds_sync();
+    X::to_lds(rg, tile, lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < NSD; ++s) gf[s] = ld_frag_nat<T>(tile, LDN, ql, 16 * s + 8 * h2);
+    wave_lds_sync();
+    X::to_lds(ro, tile, lane);
+    wave_lds_sync();
+    // delta[q] = sum_d dO[q, d] O[q, d] from the fragments (published for the dK / dV kernel that may run next)
+    float dpart = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSD; ++s) {
+      Pack8<T> g, o;
+      g.v = gf[s];
+      o.v = ld_frag_nat<T>(tile, LDN, ql, 16 * s + 8 * h2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dpart += to_f(g.e[j]) * to_f(o.e[j]);
+    }
+    const float dlt = halves_sum(dpart);
+    if (qb + (int)gridDim.x < nqb) fetch(qb + gridDim.x);
+    if (qok && h2 == 0) p.delta[stat] = dlt;
+    const float cl = qok ? -p.lse[stat] / p.scale : 0.f, cd = qok ? -dlt : 0.f;
+
+    f32x16 dq[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 3; ++sub) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = cl;
+        dp[r] = cd;
+      }
+#pragma unroll
+      for (int s = 0; s < NSD; ++s) {
+        const auto kf = ld_frag_nat<T>(Ks, LDN, sub * 32 + ql, 16 * s + 8 * h2);
+        st = TT<T>::mfma32(kf, qf[s], st);
+        const auto vf = ld_frag_nat<T>(Vs, LDN, sub * 32 + ql, 16 * s + 8 * h2);
+        dp = TT<T>::mfma32(vf, gf[s], dp);
+      }
+      // keys 80..95 (registers 8..15 of the third sub-tile) do not exist for the 77 text tokens: skipped (wave-uniform)
+      const bool half2 = sub < 2 || p.Nk > 80;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * sl) * dp[r];  // dS^T = P^T o (dP^T - delta)
+      if (half2) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 8; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * sl) * dp[r];
+      }
+      if (sub * 32 + 32 > p.Nk) {  // keys that do not exist: dS = 0 (their p = exp(-lse) can leave the fp16 range)
+        asm volatile("" ::: "memory");  // keeps the scalar branch
+        const int lim = p.Nk - sub * 32 - 4 * h2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = ((r & 3) + 8 * (r >> 2) >= lim) ? 0.f : st[r];
+      }
+      auto dq_step = [&](int s2) {
+        const auto df = pack8<T>(st, s2);
+        const int kb = sub * 32 + s2 * 16 + 4 * h2;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const auto kf = ld_frag_trhw<T>(Ks2, LDV, kb, i * 32, lane);
+          dq[i] = TT<T>::mfma32(kf, df, dq[i]);
+        }
+      };
+      dq_step(0);
+      if (half2) {
+        asm volatile("" ::: "memory");
+        dq_step(1);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Pack4<T> t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t.e[j] = from_f<T>(dq[i][4 * g + j] * p.scale);
+        *reinterpret_cast<u32x2*>(tile + ql * LDN + i * 32 + 8 * g + 4 * h2) = t.u;
+      }
+    wave_lds_sync();
+    X::store_rows(tile, rD, q0, p.Nq, p.lddq, col0, p.D, lane);
+    wave_lds_sync();
+  }
+}
+
+// query blocks chained per workgroup: enough workgroups to fill the chip a few times over, K / V staged once per chain
+static int xs_grid_x(const AttnParams& p) {
+  const int nqb = cdiv(p.Nq, 128);
+  const int64_t heads = (int64_t)p.H * p.B;
+  int chain = 1;
+  // measured (tools/bench_attn.py --xs, SMI_XS_CHAIN sweep): chaining pays while >= 5 workgroups per CU remain
+  while (chain < 4 && nqb % (2 * chain) == 0 && heads * (nqb / (2 * chain)) >= 1280) chain *= 2;
+  static const int forced = []() { const char* e = getenv("SMI_XS_CHAIN"); return e ? atoi(e) : 0; }();  // (experiments)
+  if (forced > 0 && nqb % forced == 0) chain = forced;
+  return nqb / chain;
+}
+
+template <typename T, int DP, int NSD>
+int xs_fwd_launch(const AttnParams& p, hipStream_t st) {
+  constexpr size_t sm = xs_fwd_smem<T, DP>();
+  if (sm > 65536) {
+    static DynLdsOnce once;
+    if (int rc = once.set((const void*)attn_xs_fwd_kernel<T, DP, NSD>, (int)sm)) return rc;
+  }
+  dim3 grid(xs_grid_x(p), p.H, p.B);
+  hipLaunchKernelGGL((attn_xs_fwd_kernel<T, DP, NSD>), grid, dim3(256), sm, st, p);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+template <typename T, int DP, int NSD>
+int xs_dq_launch(const AttnParams& p, hipStream_t st) {
+  constexpr size_t sm = xs_dq_smem<T, DP>();
+  if (sm > 65536) {
+    static DynLdsOnce once;
+    if (int rc = once.set((const void*)attn_xs_bwd_dq_kernel<T, DP, NSD>, (int)sm)) return rc;
+  }
+  dim3 grid(xs_grid_x(p), p.H, p.B);
+  hipLaunchKernelGGL((attn_xs_bwd_dq_kernel<T, DP, NSD>), grid, dim3(256), sm, st, p);
+  SMI_HIP(hipGetLastError());
+  return 0;
+}
+// SMI_ATTN_XS=0: short key sequences through the generic tiled kernels (A/B)
+static bool xs_enabled() {
+  static const bool on = []() { const char* e = getenv("SMI_ATTN_XS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <typename T, int DP>
 size_t dkv_smem() {
   return (size_t)(2 * TK * Stage<T, DP>::LDN + 2 * TK * Stage<T, DP>::LDV) * sizeof(T) + 2 * TK * sizeof(float);
@@ -733,6 +1161,10 @@ int fwd_t(const AttnParams& p, hipStream_t st) {
   static const bool pre = []() { const char* e = getenv("SMI_ATTN_PRESCALE"); return e && e[0] == '1'; }();
   // PRE re-rounds Q (x scale log2 e) to the storage type: 2^-11 in fp16, 2^-9 in bf16 -- fp16 only
   constexpr bool is_f16 = sizeof(T) == 2 && std::is_same<T, f16>::value;
+  if (p.Nk <= XS_KEYS && xs_enabled()) {  // all keys at once (cross-attention on the text tokens)
+    if (nsd == NS) return xs_fwd_launch<T, DP, NS>(p, st);
+    if (ALT > 0 && nsd == ALT) return xs_fwd_launch<T, DP, (ALT > 0 ? ALT : NS)>(p, st);
+  }
   if constexpr (DP <= 64 && is_f16) {
     if (p.D == DP && pre) {
       hipLaunchKernelGGL((attn_fwd_kernel<T, DP, NS, true>), grid, dim3(256), 0, st, p);
@@ -772,7 +1204,10 @@ int bwd_t(const AttnParams& p, hipStream_t st) {
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, st, p);
   }
-  if (p.dQ) {
+  if (p.dQ && p.Nk <= XS_KEYS && xs_enabled() && form != 0) {
+    if (form == 1) { if (xs_dq_launch<T, DP, NS>(p, st)) return -2; }
+    else { if (xs_dq_launch<T, DP, ALTC>(p, st)) return -2; }
+  } else if (p.dQ) {
     dim3 grid(cdiv(p.Nq, 128), p.H, p.B);
     static const bool remat = []() { const char* e = getenv("SMI_ATTN_DQ_REMAT"); return e && e[0] == '1'; }();
     if (form == 1 && remat)

@@ -84,6 +84,18 @@ __global__ void pack_conv_kernel(const T* __restrict__ src, T* __restrict__ dst,
     }
   }
 }
+// up to 64 floats handed over BY VALUE in the kernel arguments (copied into the kernarg segment at launch), written to one
+// or two device tables: host values reach the device without a host buffer that must outlive the call
+struct F64Args {
+  float v[64];
+};
+__global__ void set_floats_kernel(float* dst0, float* dst1, F64Args a, int n) {
+  const int i = threadIdx.x;
+  if (i < n) {
+    dst0[i] = a.v[i];
+    if (dst1) dst1[i] = a.v[i];
+  }
+}
 __global__ void fill_kernel(float* p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -357,6 +369,7 @@ struct smi_engine {
       if ((call) != 0) {                   \
         err = true;                        \
       }                                    \
+      bound_queue_depth();                 \
     }                                      \
   } while (0)
   // same, attributing the launch (and its algorithmic FLOPs / HBM bytes) to a kernel class for smi_profile_*
@@ -370,11 +383,24 @@ struct smi_engine {
       }                                    \
       if (trace_launches) trace_after();   \
       prof_end();                          \
+      bound_queue_depth();                 \
     }                                      \
   } while (0)
   // SMI_TRACE_LAUNCH=1 (debugging a hang): names every launch on stderr and waits for it, so the last line printed is the
   // launch that never came back
   bool trace_launches = getenv("SMI_TRACE_LAUNCH") != nullptr;
+  // SMI_SYNC_EVERY=N: wait for the stream after every N launches, i.e. never more than N (x 3 with the profiling events)
+  // AQL packets of ours outstanding.  For `rocprofv3 --pmc` runs: counter collection serialises dispatches behind its own
+  // start / stop / read packets, the HIP runtime's queue backs up at our launch rate, and with some hundred packets
+  // outstanding the profiler's intercept queue aborted once on a packet it had not finished rewriting
+  int sync_every = getenv("SMI_SYNC_EVERY") ? atoi(getenv("SMI_SYNC_EVERY")) : 0;
+  int launches_since_sync = 0;
+  void bound_queue_depth() {
+    if (sync_every > 0 && ++launches_since_sync >= sync_every) {
+      launches_since_sync = 0;
+      (void)hipStreamSynchronize(stream);
+    }
+  }
   void trace_before(const char* what) {
     fprintf(stderr, "[smi launch] %.110s ...", what);
     fflush(stderr);
@@ -2554,13 +2580,16 @@ int smi_unet_forward_multi(smi_engine* e, int n, int n_adapted, const float* sam
   SMI_CHECK(e->n_conv_sites == 0 && e->dora_sites.empty(),
             "per-sample multipliers are implemented for Linear LoRA sites (attention projections, time_emb_proj, "
             "conv_shortcut); this network has conv or DoRA sites -- run the samples in separate passes");
-  float sig[smi_engine::MAXS];
-  for (int i = 0; i < n_adapted; ++i) sig[i] = multipliers[i] / mref;
-  // (tiny, from pageable host memory: the copy is staged before this returns, ordered on the engine's stream)
-  SMI_HIP(hipMemcpyAsync(e->samp_mult_dev, sig, n_adapted * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  if (save_for_backward)
-    SMI_HIP(hipMemcpyAsync(e->samp_mult_dev + smi_engine::MAXS, sig, n_adapted * sizeof(float), hipMemcpyHostToDevice,
-                           e->stream));
+  // the per-sample ratios travel in kernel arguments, 64 per launch, ordered on the engine's stream (an async
+  // copy from a stack array is only correct while the runtime stages pageable sources before returning)
+  for (int i0 = 0; i0 < n_adapted; i0 += 64) {
+    F64Args a;
+    const int cnt = n_adapted - i0 < 64 ? n_adapted - i0 : 64;
+    for (int i = 0; i < 64; ++i) a.v[i] = i < cnt ? multipliers[i0 + i] / mref : 0.f;
+    hipLaunchKernelGGL(set_floats_kernel, dim3(1), dim3(64), 0, e->stream, e->samp_mult_dev + i0,
+                       save_for_backward ? e->samp_mult_dev + smi_engine::MAXS + i0 : (float*)nullptr, a, cnt);
+  }
+  SMI_HIP(hipGetLastError());
   e->samp_on = true;
   const int rc = smi_unet_forward_batched(e, n, n_adapted, sample, timestep, ctx, text_embeds, time_ids, lora_down_flat,
                                           lora_up_flat, mref, save_for_backward, eps_out);

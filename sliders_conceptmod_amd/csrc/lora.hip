@@ -408,15 +408,27 @@ int launch_lora_skinny(int dtype, const void* X, int64_t ldx, const void* S, flo
   SMI_CHECK(!row_mul || rows_per_mul > 0, "lora_skinny: rows_per_mul must be positive");
   SMI_CHECK(lora_skinny_supported(X, ldx, S, out, ldo, M, R, K), "lora_skinny: unsupported layout (R=%d K=%d)", R, K);
   const int grid = cdiv(M, 16);
-#define GO(TT_, NF_)                                                                                          \
-  hipLaunchKernelGGL((lora_skinny_kernel<TT_, NF_, 8>), dim3(grid), dim3(256), 0, stream, (const TT_*)X, ldx, \
+  // STEPS = 32-wide k-steps whose loads a wave issues before its first MFMA.  The grid is one 4-wave workgroup per 16 rows
+  // (M = 4096: one per CU), so the launch lasts as many memory round trips as the k loop has iterations: with the UNet's
+  // widths (K = 1280 / 640: 10 / 5 steps per wave) ONE iteration holds the whole row slice in flight -- 7.1 -> ~4 us per
+  // launch, 280 launches per step.  Same MFMA chain per wave whatever the grouping: results do not change.
+  const int ksteps = (K >> 2) / 32;
+#define GO3(TT_, NF_, ST_)                                                                                       \
+  hipLaunchKernelGGL((lora_skinny_kernel<TT_, NF_, ST_>), dim3(grid), dim3(256), 0, stream, (const TT_*)X, ldx, \
                      (const TT_*)S, out, ldo, M, K, row_mul, rows_per_mul)
+#define GO(TT_, NF_)                         \
+  do {                                       \
+    if (ksteps == 10) GO3(TT_, NF_, 10);     \
+    else if (ksteps == 5) GO3(TT_, NF_, 5);  \
+    else GO3(TT_, NF_, 8);                   \
+  } while (0)
   if (dtype == DT_F16) {
     if (R == 16) GO(f16, 1); else GO(f16, 2);
   } else {
     if (R == 16) GO(bf16, 1); else GO(bf16, 2);
   }
 #undef GO
+#undef GO3
   SMI_HIP(hipGetLastError());
   return 0;
 }

@@ -45,11 +45,14 @@ class SliderStep:
         # per step.  Off by default: the reference runs all of them, so the headline number does too.
         self.dedup = bool(dedup_uncond and batch_passes and not self.skip_dead)
         flat = network.flat
-        self.grad = torch.zeros_like(flat)
+        # ONE message per step: [flat fp32 LoRA gradient | loss scalar] -- the loss rides on the
+        # gradient's all-reduce
+        self.msg = torch.zeros(flat.numel() + 1, dtype=flat.dtype, device=flat.device)
+        self.grad = self.msg[:flat.numel()]
+        self.loss = self.msg[flat.numel():]
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.scratch = torch.empty(4096, dtype=torch.float32, device=flat.device)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.step_count = 0
         self._lib = _native.lib()
 
@@ -237,8 +240,7 @@ class SliderStep:
         self.grad.zero_()
         n_down = net._n_down
         engine.backward(d_eps, self.grad[:n_down], self.grad[n_down:])
-        parallel.allreduce_mean_(self.grad, self.pg)  # no-op on a single rank
-        parallel.allreduce_mean_(self.loss, self.pg)
+        parallel.allreduce_mean_(self.msg, self.pg)  # gradient + loss in one collective; no-op on a single rank
         self.step_count += 1
         flat = net.flat
         _native.check(self._lib.smi_clip_adamw(_native.ptr(flat), _native.ptr(self.grad), _native.ptr(self.exp_avg),
@@ -271,11 +273,13 @@ class ImageSliderStep:
         self.one_pass = one_pass  # both sides in one UNet pass where the adaptor set allows it (see _one_pass_ok)
         self._one_pass_cached = None
         flat = network.flat
-        self.grad = torch.zeros_like(flat)
+        # one message per step: [flat fp32 LoRA gradient | loss of the high side, loss of the low side]
+        self.msg = torch.zeros(flat.numel() + 2, dtype=flat.dtype, device=flat.device)
+        self.grad = self.msg[:flat.numel()]
+        self.losses = self.msg[flat.numel():]  # (high side, low side); mean over ranks after the step's all-reduce
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.scratch = torch.empty(4096, dtype=torch.float32, device=flat.device)
-        self.losses = torch.zeros(2, dtype=torch.float32, device=flat.device)  # (high side, low side)
         self.step_count = 0
         self._lib = _native.lib()
 
@@ -363,7 +367,7 @@ class ImageSliderStep:
             self._side(0, +scale, noised_high, noise_high, timestep, cond_pos, guidance_scale)
             self._side(1, -scale, noised_low, noise_low, timestep, cond_neu, guidance_scale)
         net.set_lora_slider(scale=1)
-        parallel.allreduce_mean_(self.grad, self.pg)
+        parallel.allreduce_mean_(self.msg, self.pg)
         self.step_count += 1
         flat = net.flat
         _native.check(self._lib.smi_clip_adamw(_native.ptr(flat), _native.ptr(self.grad), _native.ptr(self.exp_avg),

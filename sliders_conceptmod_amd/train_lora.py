@@ -30,7 +30,10 @@ def encode(text_encoder, tokenizer, prompt, device, dtype):
 
 
 def train(config: RootConfig, prompts: list, device, models=None, on_step_complete=None, save_file=True,
-          fused_step: bool = False):
+          fused_step=None, dedup_uncond: bool = True):
+    """`fused_step` (not in the reference signature): None (default) = the fused path whenever the configured optimiser is
+    Adam / AdamW, else the reference-style autograd loop; True = fused or ValueError; False = the reference-style loop.
+    `dedup_uncond`: inside the fused step, run each distinct frozen sample once (bit-identical results, step.py)."""
     metadata = {"prompts": ",".join([p.model_dump_json() for p in prompts]), "config": config.model_dump_json()}
     save_path = Path(config.save.path)
     # train_lora.py:44-46: `modules = DEFAULT_TARGET_REPLACE; modules += UNET_TARGET_REPLACE_MODULE_CONV` mutates the list
@@ -84,18 +87,20 @@ def train(config: RootConfig, prompts: list, device, models=None, on_step_comple
                                                  settings=settings))
     del tokenizer, text_encoder
 
-    # --fused_step: the pre-roll and the 4-pass step run through SliderStep (one batched UNet pass, native loss / AdamW,
-    # no autograd graph) -- the path bench.py measures.  Same arithmetic and RNG draw order as the loop below (tested).
+    # The fused step (default): the pre-roll and the 4-pass step run through SliderStep (one batched UNet pass, native loss /
+    # AdamW, no autograd graph) -- the path bench.py measures.  Same arithmetic and RNG draw order as the loop below
+    # (tested); `--no_fused_step` keeps the reference-style loop.
     stepper = None
-    if fused_step:
+    name = config.train.optimizer.lower()
+    wd = optimizer_kwargs.get("weight_decay", 1e-2 if name == "adamw" else 0.0)
+    fusable = name in ("adam", "adamw") and not (name == "adam" and wd != 0.0) and not optimizer_kwargs.get("amsgrad")
+    if fused_step and not fusable:
+        raise ValueError("--fused_step implements Adam / AdamW (decoupled weight decay) only")
+    if fused_step or (fused_step is None and fusable):
         from .step import SliderStep
-        name = config.train.optimizer.lower()
-        wd = optimizer_kwargs.get("weight_decay", 1e-2 if name == "adamw" else 0.0)
-        if name not in ("adam", "adamw") or (name == "adam" and wd != 0.0) or optimizer_kwargs.get("amsgrad"):
-            raise ValueError("--fused_step implements Adam / AdamW (decoupled weight decay) only")
         stepper = SliderStep(unet, network, noise_scheduler, lr=config.train.lr, weight_decay=wd,
                              eps=optimizer_kwargs.get("eps", 1e-8), betas=optimizer_kwargs.get("betas", (0.9, 0.999)),
-                             max_grad_norm=0.0, cfg_scale=1.0)
+                             max_grad_norm=0.0, cfg_scale=1.0, dedup_uncond=dedup_uncond)
     cond_cache = {}
 
     pbar = tqdm(range(config.train.iterations), disable=rank != 0)
@@ -214,7 +219,21 @@ def main(args):
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     else:
         device = torch.device(f"cuda:{args.device}")
-    train(config, prompts, device, fused_step=args.fused_step)
+    train(config, prompts, device, fused_step=args.fused_step, dedup_uncond=not args.no_dedup_uncond)
+
+
+def add_fused_step_flags(parser):
+    """Shared by the four trainers: the fused step is the default, `--no_fused_step` keeps the reference-style loop."""
+    g = parser.add_mutually_exclusive_group()
+    g.add_argument("--fused_step", dest="fused_step", action="store_true", default=None,
+                   help="insist on the fused step (pre-roll + 4-pass step through step.SliderStep / ImageSliderStep: one "
+                        "batched UNet pass, native loss / clip / AdamW, no autograd graph -- the path bench.py measures); "
+                        "it is the default whenever the optimiser is Adam / AdamW")
+    g.add_argument("--no_fused_step", dest="fused_step", action="store_false",
+                   help="the reference-style loop: one UNet call per guidance pass, torch autograd and optimiser")
+    parser.add_argument("--no_dedup_uncond", action="store_true",
+                        help="fused step: run the unconditional half of every frozen pass again, as the reference does, "
+                             "instead of once (results are bit-identical either way)")
 
 
 def build_parser():
@@ -226,9 +245,7 @@ def build_parser():
     parser.add_argument("--name", type=str, required=False, default=None, help="Name of the slider.")
     parser.add_argument("--attributes", type=str, required=False, default=None,
                         help="attritbutes to disentangle (comma seperated string)")
-    parser.add_argument("--fused_step", action="store_true",
-                        help="run the pre-roll and the 4-pass step through SliderStep (one batched UNet pass, native "
-                             "loss / AdamW, no autograd graph) -- the path bench.py measures")
+    add_fused_step_flags(parser)
     return parser
 
 

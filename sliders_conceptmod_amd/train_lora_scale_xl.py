@@ -13,6 +13,7 @@ names.  Image files (.png / .jpg / .jpeg / .webp) are resized and VAE-encoded ev
 (`train_util.get_noisy_image`, I/train_lora-scale-xl.py:216-247) on the HIP VAE encoder; `<name>.pt` / `.safetensors`
 tensors [4, h, w] are taken as PRE-ENCODED latents (already multiplied by the VAE scaling factor)."""
 import argparse
+import ast
 import os
 import random
 from pathlib import Path
@@ -70,12 +71,13 @@ _IMAGE_EXT = (".png", ".jpg", ".jpeg", ".webp")  # I/train_lora-scale-xl.py:217
 
 
 def train(config, prompts, device, folder_main, folders, scales, models=None, rank=4, vae=None, image_size=None,
-          xl=True, fused_step: bool = False, on_step_complete=None):
+          xl=True, fused_step=None, on_step_complete=None):
     """`vae` (an AutoencoderKL, default: loaded next to the UNet) is only needed when the folders hold image files;
     `image_size` is what the pairs are resized to (the reference hard-codes (512, 512) for SD-XL,
     I/train_lora-scale-xl.py:220, and (256, 256) for SD-1.x, I/train_lora-scale.py:219).  `xl=False` is the SD-1.x twin
     (train_lora_scale.py).  `fused_step` runs the two-sided step through step.ImageSliderStep (no autograd graph, native
-    AdamW) -- same arithmetic, tested against the autograd loop."""
+    AdamW) -- same arithmetic, tested against the autograd loop: None (default) = whenever the configured optimiser is
+    Adam / AdamW without amsgrad, True = fused or ValueError, False = the reference-style autograd loop."""
     weight_dtype = config_util.parse_precision(config.train.precision)
     tokenizers, text_encoders, unet, noise_scheduler = models or model_util.load_models(
         config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler, xl=xl)
@@ -95,8 +97,13 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
                           train_method=config.network.training_method, target_replace=modules).to(device,
                                                                                                    dtype=weight_dtype)
     parallel.broadcast_(network.flat.data)
+    optimizer_kwargs = {}  # I/train_lora-scale-xl.py:110-117: "k=v k=v" -> keyword arguments of the optimiser
+    if config.train.optimizer_args is not None and len(config.train.optimizer_args) > 0:
+        for arg in config.train.optimizer_args.split(" "):
+            key, value = arg.split("=")
+            optimizer_kwargs[key] = ast.literal_eval(value)
     optimizer = train_util.get_optimizer(config.train.optimizer)(network.prepare_optimizer_params(),
-                                                                 lr=config.train.lr)
+                                                                 lr=config.train.lr, **optimizer_kwargs)
     lr_scheduler = train_util.get_lr_scheduler(config.train.lr_scheduler, optimizer,
                                                max_iterations=config.train.iterations, lr_min=config.train.lr / 100)
     # every prompt entry is encoded (target / positive / neutral / unconditional, I/train_lora-scale-xl.py:136-166) and one
@@ -138,12 +145,17 @@ def train(config, prompts, device, folder_main, folders, scales, models=None, ra
     save_path = Path(config.save.path)
     save_dtype = config_util.parse_precision(config.train.precision)
     stepper = None
-    if fused_step:
+    oname = config.train.optimizer.lower()
+    wd = optimizer_kwargs.get("weight_decay", 1e-2 if oname == "adamw" else 0.0)
+    unsupported = set(optimizer_kwargs) - {"weight_decay", "betas", "eps", "amsgrad"}
+    fusable = (oname in ("adam", "adamw") and not (oname == "adam" and wd != 0.0) and not optimizer_kwargs.get("amsgrad")
+               and not unsupported)
+    if fused_step and not fusable:
+        raise ValueError("--fused_step implements Adam / AdamW (decoupled weight decay; weight_decay, betas, eps) only")
+    if fused_step or (fused_step is None and fusable):
         from .step import ImageSliderStep
-        if config.train.optimizer.lower() not in ("adam", "adamw"):
-            raise ValueError("--fused_step implements Adam / AdamW only")
-        stepper = ImageSliderStep(unet, network, noise_scheduler, lr=config.train.lr,
-                                  weight_decay=1e-2 if config.train.optimizer.lower() == "adamw" else 0.0)
+        stepper = ImageSliderStep(unet, network, noise_scheduler, lr=config.train.lr, weight_decay=wd,
+                                  eps=optimizer_kwargs.get("eps", 1e-8), betas=optimizer_kwargs.get("betas", (0.9, 0.999)))
     cond_cache = {}
     network.training_losses = []
     for i in tqdm(range(config.train.iterations), disable=rank_ != 0):
@@ -246,7 +258,7 @@ def main(args, xl: bool = True, models=None, vae=None):
     folders = [f.strip() for f in args.folders.split(",")]
     scales = [float(s.strip()) for s in args.scales.split(",")]
     return train(config, prompts, device, args.folder_main, folders, scales, rank=args.rank, xl=xl, models=models,
-                 vae=vae, fused_step=getattr(args, "fused_step", False))
+                 vae=vae, fused_step=getattr(args, "fused_step", None))
 
 
 def build_parser():
@@ -261,8 +273,8 @@ def build_parser():
     p.add_argument("--stylecheck", type=str, default=None)
     p.add_argument("--folders", type=str, default="verylow, low, high, veryhigh")
     p.add_argument("--scales", type=str, default="-2, -1, 1, 2")
-    p.add_argument("--fused_step", action="store_true",
-                   help="run the two-sided step through ImageSliderStep (no autograd graph, native AdamW)")
+    from .train_lora import add_fused_step_flags
+    add_fused_step_flags(p)  # (--no_dedup_uncond is accepted and has no effect here: the image step has no frozen passes)
     return p
 
 

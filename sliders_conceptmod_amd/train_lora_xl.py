@@ -4,8 +4,9 @@ clip_grad_norm_ 0.2, `.safetensors` output, `on_step_complete` callback, in-memo
 
     python -m sliders_conceptmod_amd.train_lora_xl --config_file cfg.yaml --alpha 1 --rank 4 --device 0 --name x
 
-`--fused_step` runs the same arithmetic through sliders_conceptmod_amd.step.SliderStep (no autograd graph, native
-loss / clip / AdamW kernels) -- the configuration bench.py measures."""
+By default the step runs through sliders_conceptmod_amd.step.SliderStep (one batched UNet pass, no autograd graph, native
+loss / clip / AdamW kernels, each distinct frozen sample once) -- the code path bench.py measures; `--no_fused_step` keeps the
+reference-style loop (one UNet call per guidance pass, torch autograd + optimiser), same arithmetic (tested)."""
 import argparse
 import os
 import sys
@@ -35,8 +36,10 @@ def encode_xl(text_encoder, tokenizer, prompt, device, dtype) -> PromptEmbedsXL:
 
 
 def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft_type="lora", rank=4, save_file=True,
-          models=None, fused_step=False, optimizer_kwargs=None):
-    """`optimizer_kwargs` (not in the reference signature) overrides keyword arguments of the hard-coded AdamW
+          models=None, fused_step=None, optimizer_kwargs=None, dedup_uncond=True):
+    """`fused_step` (not in the reference signature): None / True = the fused path (the script's optimiser is a hard-coded
+    AdamW, train_lora_xl.py:104), False = the reference-style autograd loop; `dedup_uncond`: inside the fused step, each
+    distinct frozen sample runs once (bit-identical results, step.py).  `optimizer_kwargs` (not in the reference signature) overrides keyword arguments of the hard-coded AdamW
     (train_lora_xl.py:104), e.g. {"eps": 1e-3} for the element-wise trajectory parity test; the per-step losses of the
     run are left in `network.training_losses`."""
     if peft_type not in ("lora", "dora"):
@@ -88,11 +91,13 @@ def train(config: RootConfig, prompts: list, device, on_step_complete=None, peft
     del tokenizers, text_encoders
 
     stepper = None
-    if fused_step:
+    if okw.get("amsgrad") and fused_step:
+        raise ValueError("--fused_step implements AdamW without amsgrad")
+    if (fused_step or fused_step is None) and not okw.get("amsgrad"):
         from .step import SliderStep
         stepper = SliderStep(unet, network, noise_scheduler, lr=okw["lr"], weight_decay=okw["weight_decay"],
                              eps=okw.get("eps", 1e-8), betas=okw.get("betas", (0.9, 0.999)), max_grad_norm=0.2,
-                             cfg_scale=guidance_scale)
+                             cfg_scale=guidance_scale, dedup_uncond=dedup_uncond)
     cond_cache = {}  # fused path: conditioning tensors per (prompt pair, batch, size); rebuilt only with dynamic crops
     network.training_losses = []
     pbar = tqdm(range(config.train.iterations), disable=rank_ != 0)
@@ -226,7 +231,8 @@ def main(args):
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     else:
         device = torch.device(f"cuda:{args.device}")
-    train(config, prompts, device, None, args.peft_type, args.rank, True, None, args.fused_step)
+    train(config, prompts, device, None, args.peft_type, args.rank, True, None, args.fused_step,
+          dedup_uncond=not args.no_dedup_uncond)
 
 
 def build_parser():
@@ -238,8 +244,8 @@ def build_parser():
     parser.add_argument("--name", type=str, required=False, default=None, help="Name of the slider.")
     parser.add_argument("--attributes", type=str, required=False, default=None)
     parser.add_argument("--peft_type", type=str, required=False, default="lora")
-    parser.add_argument("--fused_step", action="store_true",
-                        help="run the 4-pass step through SliderStep (native loss/clip/AdamW, no autograd graph)")
+    from .train_lora import add_fused_step_flags
+    add_fused_step_flags(parser)
     return parser
 
 

@@ -290,9 +290,11 @@ def test_image_slider_step_real_sdxl_widths_vs_oracle():
     assert eg < GRAD_BAR, eg
 
 
-def test_kernel_generations_agree_at_headline_size(tmp_path):
-    """Size-independent property at BASELINE's full size (SD-XL 1024^2, B = 2, rank 4: 16 UNet samples per pass, where
-    the CPU oracle would need hours): every GEMM generation accumulates over K in the same order and applies the same
+@pytest.mark.parametrize("config", ["sdxl_1024_b2_r4", "sd14_512_b1_r4", "sd15_512_b4_r4", "sd14_512_b1_r4_c3lier"])
+def test_kernel_generations_agree_at_headline_size(tmp_path, config):
+    """Size-independent property at BASELINE's full sizes (C3: SD-XL 1024^2, B = 2, rank 4 -- 16 UNet samples per pass, where
+    the CPU oracle would need hours; C1 / C2: SD-1.x 512^2 at B = 1 fp16 / B = 4 bf16, whose shapes -- head_dim 40 at 4096
+    tokens, the split-K convs 128 x 1280 x 11520 -- differ from SD-XL's; and the shipped c3lier adaptor set): every GEMM generation accumulates over K in the same order and applies the same
     epilogue arithmetic, so a whole train step run with the tile selection forced to the plain 128 x 128 LDS-DMA kernel
     must give the SAME loss, LoRA gradient and updated parameters as the default selection (the tuned mix of the
     256 x 320 persistent kernel, the 256 x 256 8-phase kernel, 128 x 160 tiles in their 4- and 8-wave forms and the
@@ -306,8 +308,8 @@ def test_kernel_generations_agree_at_headline_size(tmp_path):
         out = tmp_path / f"{name}.pt"
         e = dict(os.environ)
         e.update(env)
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fullsize_digest.py"), "--out", str(out)],
-                           env=e, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fullsize_digest.py"), "--out", str(out),
+                            "--config", config], env=e, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(torch.load(out, weights_only=True))
     a, b = outs

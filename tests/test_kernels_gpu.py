@@ -270,6 +270,44 @@ def test_attention_rescale_branch_with_spiked_key(lib, dt):
     torch.testing.assert_close(lse, lref, rtol=1e-4, atol=2e-3)  # what the backward recomputes P against
 
 
+@pytest.mark.parametrize("Nq,Nk,D", [(192, 77, 64), (128, 77, 40), (64, 130, 64)])
+def test_attention_backward_padded_keys_with_negative_lse(lib, Nq, Nk, D):
+    """keys past Nk in the ragged last tile get p = exp(-lse); with every logit strongly negative (lse < -10) and
+    a large (loss-scaled) dO their dS left the fp16 range and inf x 0 = NaN entered dQ.  fp16, dQ finite and == fp32 torch."""
+    dt = torch.float16
+    B, H = 2, 3
+    # one unit direction u per (batch, head): q = 5 sqrt(D) u + noise, k = -6 u + unit noise  =>  scale * q . k ~ -30 +- 5
+    # (the common component of k stays below its noise, so dQ = sum_k dS_k k_k is well conditioned: 5e-4 on an fp32 emulation)
+    u = rnd(B, 1, H, D, dt=torch.float32, seed=7)
+    u = u / u.norm(dim=-1, keepdim=True)
+    q = (5.0 * D ** 0.5 * u + 0.3 * rnd(B, Nq, H, D, dt=torch.float32, seed=1)).to(dt)
+    k = (-6.0 * u + rnd(B, Nk, H, D, dt=torch.float32, seed=2)).to(dt)
+    v = rnd(B, Nk, H, D, dt=dt, seed=3)
+    scale = D ** -0.5
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, Nq, device="cuda")
+    chk(lib, lib.smi_op_attention_fwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), B, H, Nq, Nk, D, scale, None))
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    oref, lref = attn_ref(qf, kf, vf, scale)
+    assert lref.max().item() < -10.0, lref.max().item()
+    close(o, oref, dt, what="attn O")
+    do = rnd(B, Nq, H, D, dt=dt, seed=4) * 512.0  # as after the engine's loss scale
+    gq, gk, gv = torch.autograd.grad(oref, (qf, kf, vf), do.float())
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Nq, device="cuda")
+    chk(lib, lib.smi_op_attention_bwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), P(do), P(dq), P(dk), P(dv), P(delta),
+                                      B, H, Nq, Nk, D, scale, None))
+    assert torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all() and torch.isfinite(dv.float()).all()
+    close(dq, gq, dt, mult=8, what="attn dQ (padded keys, lse < -10)")
+    close(dk, gk, dt, mult=8, what="attn dK")
+    close(dv, gv, dt, mult=8, what="attn dV")
+    # and the dQ-only form the engine uses for cross-attention under `noxattn` (no dK / dV asked)
+    dq2 = torch.empty_like(q)
+    chk(lib, lib.smi_op_attention_bwd(dcode(dt), P(q), P(k), P(v), P(o), P(lse), P(do), P(dq2), None, None, P(delta),
+                                      B, H, Nq, Nk, D, scale, None))
+    assert torch.equal(dq2, dq)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("nb,HW,Cc,G,silu", [(2, 256, 320, 32, 1), (3, 64, 64, 16, 0), (2, 1000, 2560, 32, 1), (1, 160 * 160, 128, 32, 1),
                                                      (2, 16384 + 40, 64, 32, 0),

@@ -1,4 +1,4 @@
-"""One headline-size slider step (SD-XL 1024^2, B = 2, rank 4, synthetic weights) -> loss, LoRA gradient and updated
+"""Full-size slider steps of a bench.py configuration (default: the headline, SD-XL 1024^2, B = 2, rank 4; synthetic weights) -> loss, LoRA gradient and updated
 parameters written to a .pt file.  Run under different SMI_GEMM settings to cross-check the kernel
 generations against each other at the real shapes (tests/test_fullsize_gpu.py)."""
 import argparse, os, sys
@@ -26,7 +26,8 @@ def main():
     bench.init_synthetic_on_device(unet, seed=0)
     unet.requires_grad_(False).eval()
     torch.manual_seed(1)
-    net = L.LoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn").to("cuda")
+    targets = list(L.DEFAULT_TARGET_REPLACE) + (list(L.UNET_TARGET_REPLACE_MODULE_CONV) if args.config.endswith("_c3lier") else [])
+    net = L.LoRANetwork(unet, rank=lrank, multiplier=1.0, alpha=1.0, train_method="noxattn", target_replace=targets).to("cuda")
     with torch.no_grad():
         net.flat_up.copy_(torch.randn(net.flat_up.shape, generator=torch.Generator().manual_seed(2)) * 1e-2)
     sched = MU.create_noise_scheduler(sched_name)
