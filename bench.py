@@ -411,6 +411,9 @@ def main():
     ap.add_argument("--skip-dead-cfg-half", action="store_true",
                     help="drop the algebraically dead unconditional half (CFG scale 1); reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="counter-collection passes (tools/collect_profiles.sh): warm-up + timed steps only -- no pre-roll, no "
+                         "HIP-event profiled step (two event packets around every launch), no CPU baseline, no JSON line")
     ap.add_argument("--separate-passes", action="store_true",
                     help="run the four guidance passes as four UNet calls instead of one batched pass")
     args = ap.parse_args()
@@ -550,6 +553,13 @@ def main():
         torch.cuda.synchronize()
         allreduce_us = ev[0].elapsed_time(ev[1]) * 1e3 / 10
     loss_val = float(loss.item())
+    if args.timed_only:
+        if rank == 0:
+            log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step (--timed-only: done)")
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     if rank == 0:
         log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step; profiling one step")
 

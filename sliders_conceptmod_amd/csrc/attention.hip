@@ -416,18 +416,21 @@ __global__ void attn_delta_kernel(AttnParams p) {
 // =============================================================================================================
 // REMAT: re-broadcast the two row constants in front of every chain (32 v_mov per 32-key sub-tile) instead of keeping
 // two 16-register copies alive across the loop (0 VALU, +32 registers: 2 waves per SIMD instead of 3)
+template <typename T, int DP>
+constexpr size_t dq_smem() {  // K and V by rows + K again at the transposed-read stride
+  return (size_t)(2 * TK * Stage<T, DP>::LDN + TK * Stage<T, DP>::LDV) * sizeof(T);
+}
+// body of the dQ workgroup (bx, head, b); `smem`: dq_smem<T, DP>() bytes
 template <typename T, int DP, int NSD, bool REMAT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, int bx, int head, int b, unsigned char* smem) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
-  __shared__ __attribute__((aligned(16))) T Ks[TK * S::LDN];
-  __shared__ __attribute__((aligned(16))) T Vs[TK * S::LDN];
-  __shared__ __attribute__((aligned(16))) T Ks2[TK * S::LDV];  // K again, at the transposed-read stride
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + TK * S::LDN;
+  T* Ks2 = Vs + TK * S::LDN;  // K again, at the transposed-read stride
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, h2 = lane >> 5;
-  int bx, head, b;
-  xcd_block(bx, head, b);
   const int q_idx = bx * 128 + wave * 32 + ql;
   const int col0 = head * p.D;
   const int nsd = NSD > 0 ? NSD : (p.D + 15) / 16;
@@ -552,6 +555,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       }
   }
 }
+template <typename T, int DP, int NSD, bool REMAT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[dq_smem<T, DP>()];
+  int bx, head, b;
+  xcd_block(bx, head, b);
+  attn_bwd_dq_body<T, DP, NSD, REMAT>(p, bx, head, b, smem);
+}
 
 // =============================================================================================================
 // backward: dK, dV.  One workgroup = 128 keys (4 waves x 32, key on the lane), sweeping 64-query tiles.
@@ -559,12 +569,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 //   dV^T[d,key] += dO^T[d,q] P[q,key] ;  dK^T[d,key] += Q^T[d,q] dS[q,key]
 // WHICH: 1 = dK only, 2 = dV only, 3 = both (register budget: both only fits for DP <= 96)
 // =============================================================================================================
-template <typename T, int DP, int WHICH, int NSD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+// OWN_DELTA: delta[q] = sum_d dO[q, d] O[q, d] of the staged queries is formed HERE (the O rows are fetched next to dO,
+// eight-lane partial dots) instead of read from p.delta: the workgroup then depends on nothing the dQ workgroups write and
+// both kinds can share one launch (attn_bwd_fused_kernel).  Needs a power-of-two chunk count per row (DP = 32 / 64).
+template <typename T, int DP, int WHICH, int NSD, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, int bx, int head, int b, unsigned char* dyn_smem) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
   constexpr bool DO_DK = (WHICH & 1) != 0, DO_DV = (WHICH & 2) != 0;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  static_assert(!OWN_DELTA || (S::CPR & (S::CPR - 1)) == 0, "OWN_DELTA: chunks per row must be a power of two");
   T* Qs = reinterpret_cast<T*>(dyn_smem);
   T* Gs = Qs + TK * S::LDN;
   T* Qs2 = Gs + TK * S::LDN;  // Q and dO again, at the transposed-read stride
@@ -574,8 +587,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kl = lane & 31, h2 = lane >> 5;
-  int bx, head, b;
-  xcd_block(bx, head, b);
   const int k_idx = bx * 128 + wave * 32 + kl;
   const int col0 = head * p.D;
   const int nsd = NSD > 0 ? NSD : (p.D + 15) / 16;
@@ -611,14 +622,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 
   const int ntiles = (p.Nq + TK - 1) / TK;
   u32x4 rq[S::NIT], rg[S::NIT];  // Q / dO tiles one tile ahead in registers
+  u32x4 ro[OWN_DELTA ? S::NIT : 1];  // OWN_DELTA: the O rows of the same tile
+  const auto rO = make_rsrc((const T*)p.O + (int64_t)b * p.Nq * p.ldo, (uint32_t)((int64_t)p.Nq * p.ldo * 2));
   float lv = 0.f, dl = 0.f;
   auto fetch = [&](int q0) {
     S::load(rq, rQ, q0, p.Nq, p.ldq, col0, p.D, tid);
     S::load(rg, rG, q0, p.Nq, p.lddo, col0, p.D, tid);
+    if constexpr (OWN_DELTA) S::load(ro, rO, q0, p.Nq, p.ldo, col0, p.D, tid);
     if (tid < TK) {
       const bool ok = q0 + tid < p.Nq;
       lv = ok ? -p.lse[stat0 + q0 + tid] * inv_scale : 0.f;  // padded queries: their Q / dO rows are zeros, any finite P does
-      dl = ok ? -p.delta[stat0 + q0 + tid] : 0.f;
+      if constexpr (!OWN_DELTA) dl = ok ? -p.delta[stat0 + q0 + tid] : 0.f;
     }
   };
   fetch(0);
@@ -631,7 +645,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     if (DO_DV) S::store_ld(rg, Gs2, S::LDV, tid);
     if (tid < TK) {
       lse_s[tid] = lv;
-      dlt_s[tid] = dl;
+      if constexpr (!OWN_DELTA) dlt_s[tid] = dl;
+    }
+    if constexpr (OWN_DELTA) {
+      // chunk i of this thread is row (tid + 256 i) / CPR of the tile, the CPR lanes of a row are adjacent: partial dot of
+      // the 8 elements, combined by butterflies inside the aligned CPR-lane group, stored (negated) by the group's first
+      // lane; rows past Nq hold zeros (-> delta 0).  The same 16-bit dO / O values as the dQ workgroups use.
+#pragma unroll
+      for (int i = 0; i < S::NIT; ++i) {
+        Pack8<T> g, o;
+        g.u = rg[i];
+        o.u = ro[i];
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += to_f(g.e[j]) * to_f(o.e[j]);
+#pragma unroll
+        for (int m = 1; m < S::CPR; m <<= 1) d += __shfl_xor(d, m);
+        const int idx = tid + 256 * i;
+        if (idx % S::CPR == 0) dlt_s[idx / S::CPR] = -d;
+      }
     }
     __syncthreads();
     if (qt + 1 < ntiles) fetch(q0 + TK);
@@ -1134,8 +1166,36 @@ static bool xs_enabled() {
 }
 
 template <typename T, int DP>
-size_t dkv_smem() {
+constexpr size_t dkv_smem() {
   return (size_t)(2 * TK * Stage<T, DP>::LDN + 2 * TK * Stage<T, DP>::LDV) * sizeof(T) + 2 * TK * sizeof(float);
+}
+template <typename T, int DP, int WHICH, int NSD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  int bx, head, b;
+  xcd_block(bx, head, b);
+  attn_bwd_dkv_body<T, DP, WHICH, NSD, false>(p, bx, head, b, dyn_smem);
+}
+
+// dQ and dK / dV of a self-attention layer in ONE launch.  Each kind alone is a grid of Nq / 128 x H x B workgroups: 640 at
+// SD-XL level 2 with 4 adapted samples -- 1.25 rounds of the 512 workgroups the chip holds at two waves per SIMD, so each
+// launch pays for two rounds; at level 1, 2.5 -> 3.  Together they are 1280 (2560) workgroups = 2.5 (5) rounds.  The
+// workgroups of a (batch, head) are adjacent in the launch order -- its key blocks (the longer ones: four products) first,
+// then its query blocks -- so the XCD that gets a contiguous range of them reads Q, K, V, dO once for both kinds.  The
+// dK / dV workgroups form delta themselves (OWN_DELTA): no workgroup waits for another.
+template <typename T, int DP, int NSD>
+__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  const int nkb = (p.Nk + 127) / 128, nqb = (p.Nq + 127) / 128, per = nkb + nqb;
+  const int total = gridDim.x, lin = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = lin & 7;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);  // XCD-contiguous order
+  const int bh = v / per, j = v - bh * per;
+  const int head = bh % p.H, b = bh / p.H;
+  if (j < nkb)
+    attn_bwd_dkv_body<T, DP, 3, NSD, true>(p, j, head, b, dyn_smem);
+  else
+    attn_bwd_dq_body<T, DP, NSD, false>(p, j - nkb, head, b, dyn_smem);
 }
 
 int check_attn(const AttnParams& p) {
@@ -1203,6 +1263,33 @@ int bwd_t(const AttnParams& p, hipStream_t st) {
     const int64_t total = (int64_t)p.B * p.H * p.Nq;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, st, p);
+  }
+  // self-attention with every gradient wanted: one launch for both kinds of workgroup (attn_bwd_fused_kernel)
+  if constexpr (DP <= 64) {
+    static const bool fused_on = []() { const char* e = getenv("SMI_ATTN_BWD_FUSED"); return !(e && e[0] == '0'); }();
+    // by measurement (tools/bench_attn.py, SMI_ATTN_BWD_FUSED=0|1): it pays on the small grids -- 4 samples x 20 heads x
+    // 1024^2: 116.8 -> 110.6 us -- and loses 3-5 % from 4096 keys on (the two kinds then fill whole rounds by themselves)
+    if (fused_on && p.dQ && p.dK && p.dV && form != 0 && p.Nk > XS_KEYS &&
+        (int64_t)cdiv(p.Nq, 128) * p.H * p.B <= 1024) {
+      constexpr size_t sm = dkv_smem<T, DP>() > dq_smem<T, DP>() ? dkv_smem<T, DP>() : dq_smem<T, DP>();
+      const int64_t total = (int64_t)(cdiv(p.Nk, 128) + cdiv(p.Nq, 128)) * p.H * p.B;
+      SMI_CHECK(total < (1ll << 31), "attention bwd: grid too large");
+      if (form == 1) {
+        if (sm > 65536) {
+          static DynLdsOnce once;
+          if (int rc = once.set((const void*)attn_bwd_fused_kernel<T, DP, NS>, (int)sm)) return rc;
+        }
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<T, DP, NS>), dim3((unsigned)total), dim3(256), sm, st, p);
+      } else {
+        if (sm > 65536) {
+          static DynLdsOnce once;
+          if (int rc = once.set((const void*)attn_bwd_fused_kernel<T, DP, ALTC>, (int)sm)) return rc;
+        }
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<T, DP, ALTC>), dim3((unsigned)total), dim3(256), sm, st, p);
+      }
+      SMI_HIP(hipGetLastError());
+      return 0;
+    }
   }
   if (p.dQ && p.Nk <= XS_KEYS && xs_enabled() && form != 0) {
     if (form == 1) { if (xs_dq_launch<T, DP, NS>(p, st)) return -2; }

@@ -122,23 +122,36 @@ def test_lora_gradients_match_oracle(model, dtype, method):
     (got * gy.cuda()).sum().backward()
     assert pnet.flat.grad is not None
     sd_g = {l.lora_name: (l.lora_down.grad, l.lora_up.grad) for l in pnet.unet_loras}
-    # per-module bar: 16-bit activation gradients + 16-bit LoRA GEMM operands; single modules with a tiny gradient
-    # norm are noise dominated in bf16 (worst seen 0.15), the global bar below is the meaningful one
-    tol = 2.5e-2 if dtype == torch.float16 else 2e-1
-    worst = 0.0
+    # Per-module bar.  A module's gradient error is noise of 16-bit activation gradients and 16-bit LoRA GEMM operands whose
+    # size follows the ACTIVATION gradients, not the module's own gradient norm: a module whose true gradient is tiny shows
+    # a large ratio to its own norm from one build to the next (0.15 <-> 0.22 on one bf16 to_v.down, round 4, with every
+    # global figure unchanged).  So a module is measured against max(its own norm, the median module norm of
+    # its kind); the global bar below is the one that tracks parity.  Bars = 1.5 x measured (round 4: fp16 per-module
+    # <= 9.6e-3, global <= 3.1e-3; bf16 <= 2.2e-1 / 2.5e-2 -- the bf16 extreme is ONE deepest-level to_v.down of the tiny
+    # SD-XL net, a sum over 32 rows; every other module is <= 6.6e-2, and the attention kernels themselves measure the same
+    # error against fp32 torch in both builds, tools/attn_err.py).
+    tol = 1.5e-2 if dtype == torch.float16 else 3.3e-1
+    worst = worst_own = 0.0
     tot_num = tot_den = 0.0
+    ref_norm = {"down": [], "up": []}
+    for lo in onet.unet_loras:
+        ref_norm["down"].append(lo.lora_down.weight.grad.norm().item())
+        ref_norm["up"].append(lo.lora_up.weight.grad.norm().item())
+    floor = {k: sorted(v)[len(v) // 2] for k, v in ref_norm.items()}
     for lo in onet.unet_loras:
         gd, gu = sd_g[lo.lora_name]
         for a, b, what in ((gd, lo.lora_down.weight.grad, "down"), (gu, lo.lora_up.weight.grad, "up")):
             assert b is not None and b.abs().max() > 0, f"oracle grad missing for {lo.lora_name}.{what}"
-            r = rel(a, b)
+            err = (a.detach().cpu() - b).norm().item()
+            r = err / max(b.norm().item(), floor[what])
             worst = max(worst, r)
-            tot_num += (a.detach().cpu() - b).norm().item() ** 2
+            worst_own = max(worst_own, err / b.norm().item())
+            tot_num += err ** 2
             tot_den += b.norm().item() ** 2
             assert r < tol, f"{lo.lora_name}.{what}: rel err {r:.3e}"
     glob = (tot_num / tot_den) ** 0.5
-    assert glob < (8e-3 if dtype == torch.float16 else 4e-2), f"global LoRA-grad rel err {glob:.3e}"
-    print(f"{model} {dtype} {method}: worst per-module grad err {worst:.2e}, global {glob:.2e}")
+    assert glob < (4.7e-3 if dtype == torch.float16 else 3.7e-2), f"global LoRA-grad rel err {glob:.3e}"
+    print(f"{model} {dtype} {method}: worst per-module grad err {worst:.2e} (vs own norm {worst_own:.2e}), global {glob:.2e}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16])
@@ -246,7 +259,8 @@ def test_rank8_and_ragged_nonsquare_latents(model):
             num += (a.detach().cpu() - b).norm().item() ** 2
             den += b.norm().item() ** 2
     glob = (num / den) ** 0.5
-    assert glob < 8e-3, f"rank-8 / ragged global LoRA-grad rel err {glob:.3e}"
+    print(f"rank-8 / ragged: global LoRA-grad rel err {glob:.2e}")
+    assert glob < 4.7e-3, f"rank-8 / ragged global LoRA-grad rel err {glob:.3e}"
 
 
 def test_alternating_resolutions_replan_without_repacking():
