@@ -30,6 +30,8 @@
 // bit-identical to the other generations: same K order per output element, same epilogue arithmetic.
 #include <mutex>
 
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #include <type_traits>
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
   // slider step) takes every tile as 192 frozen + 64 adapted rows -- A unit u (= wave row u) is 48 frozen rows + 16
   // adapted ones, so each wave's fourth m-fragment is the adapted one and the delta's epilogue cost is spread evenly
   // over all tiles and waves instead of quadrupling the epilogue of a quarter of the tiles (the launch waits for those).
-  const bool mix = !CONV && p.lora_r > 0 && p.lora_row0 > 0 && 4 * (int64_t)p.lora_row0 == 3 * (int64_t)p.M;
+  const bool mix = !CONV && !UPS && p.lora_r > 0 && p.lora_row0 > 0 && 4 * (int64_t)p.lora_row0 == 3 * (int64_t)p.M;
   const int lda = (CONV || UPS) ? p.Cin : (int)p.lda;  // elements between consecutive A rows (conv: NHWC pixels are contiguous)
   const bool arow = mix && wave >= 6;  // this wave stages the adapted rows of a unit (wave-uniform)
   const uint32_t voffA = (uint32_t)(arow ? r64 - 48 : r64) * (uint32_t)(lda * 2) + chunk * 16;
@@ -621,6 +623,17 @@ bool gemm2_supported(const GemmParams& p);
 // dense GEMMs and plain 3x3 convs on whole 256 x 320 tiles
 bool gemm4_supported(const GemmParams& p) {
   if (!gemm2_supported(p)) return false;
+  {  // SMI_G4_DENY (debugging): bit mask of launch classes kept off this kernel
+    static const int deny = []() { const char* e = getenv("SMI_G4_DENY"); return e ? atoi(e) : 0; }();
+    if ((deny & 1) && p.conv && !p.upsample && p.lora_r > 0) return false;
+    if ((deny & 2) && p.conv && p.Cin == 64) return false;
+    if ((deny & 4) && p.conv && p.upsample && p.lora_r > 0) return false;
+    if ((deny & 8) && !p.conv && p.lora_r > 0 && p.lora_row0 > 0) return false;
+    if ((deny & 16) && p.conv && p.res == p.C && p.res) return false;
+    if ((deny & 32) && p.conv && p.upsample) return false;
+    if ((deny & 64) && p.conv) return false;
+    if ((deny & 128) && !p.conv && p.lora_r > 0) return false;
+  }
   if (p.geglu_out && (p.conv || p.out_f32 || p.res || p.rowvec || p.lora_r > 0 ||
                       (reinterpret_cast<uintptr_t>(p.geglu_out) & 15) != 0))
     return false;

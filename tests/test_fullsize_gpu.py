@@ -304,7 +304,11 @@ def test_kernel_generations_agree_at_headline_size(tmp_path, config):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for name, env in (("default", {}), ("plain", {"SMI_GEMM": "128"})):
+    # third arm: EVERY launch the 256 x 320 persistent kernel supports forced onto it (the tuner only puts a shape there when
+    # it wins the timing) -- round 4: this is what exposed its up-sampler conv mode taking the batched-pass LoRA epilogue's
+    # interleaved row map (`mix`), which the shipped c3lier adaptor set reaches from 64-pixel-wide maps on
+    arms = [("default", {}), ("plain", {"SMI_GEMM": "128"}), ("gemm4", {"SMI_GEMM": "5ph"})]
+    for name, env in arms:
         out = tmp_path / f"{name}.pt"
         e = dict(os.environ)
         e.update(env)
@@ -312,8 +316,9 @@ def test_kernel_generations_agree_at_headline_size(tmp_path, config):
                             "--config", config], env=e, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(torch.load(out, weights_only=True))
-    a, b = outs
-    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    a = outs[0]
     assert torch.isfinite(a["grad"]).all() and float(a["grad"].abs().max()) > 0
-    assert torch.equal(a["grad"], b["grad"]), f"max |diff| {float((a['grad'] - b['grad']).abs().max()):.3e}"
-    assert torch.equal(a["flat"], b["flat"])
+    for (name, _), b in zip(arms[1:], outs[1:]):
+        assert a["losses"] == b["losses"], (name, a["losses"], b["losses"])
+        assert torch.equal(a["grad"], b["grad"]), f"{name}: max |diff| {float((a['grad'] - b['grad']).abs().max()):.3e}"
+        assert torch.equal(a["flat"], b["flat"]), name
