@@ -576,6 +576,16 @@ def main():
     pre_step.preroll(denoised, cond, n_pre, 3.0)
     torch.cuda.synchronize()
     preroll_ms = (time.perf_counter() - t0) * 1e3
+    # the SD-XL trainer's DEFAULT pre-roll runs at guidance scale train.cfg = 1.0 (T/config_util.py:41), where the
+    # unconditional half of the doubled batch is algebraically dead and SliderStep.preroll runs the conditional half alone
+    preroll_cfg1_ms = None
+    if xl:
+        pre_step.preroll(denoised, cond, 1, 1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pre_step.preroll(denoised, cond, n_pre, 1.0)
+        torch.cuda.synchronize()
+        preroll_cfg1_ms = (time.perf_counter() - t0) * 1e3
     if os.environ.get("SMI_BENCH_PROFILE_PREROLL") == "1":  # per-shape table of ONE pre-roll forward (with SMI_PROF_DUMP=1)
         unet._engine.profile_enable(True)
         pre_step.preroll(denoised, cond, 1, 3.0)
@@ -625,7 +635,11 @@ def main():
                         "~0.1 % of a step)"},
             "loss": loss_val,
             "preroll": {"forwards": n_pre, "ms": preroll_ms, "unet_batch": 2 * B,
-                        "note": "no-grad diffusion(_xl) pre-roll at its mean length, adaptor on; NOT part of `value`",
+                        "note": "no-grad diffusion(_xl) pre-roll at its mean length, adaptor on, guidance scale 3 (doubled "
+                                "batch); NOT part of `value`",
+                        "ms_at_guidance_1": preroll_cfg1_ms,
+                        "note_guidance_1": "the SD-XL trainer's default train.cfg = 1.0: the conditional half alone "
+                                           "(UNet batch B), the unconditional half being algebraically dead there",
                         "steps_per_s_with_preroll": world / ((ms_per_step + preroll_ms) * 1e-3)},
             "step_algorithmic_tflop": step_flops / 1e12,
             "step_tflops_achieved": step_flops / 1e12 / (ms_per_step * 1e-3),

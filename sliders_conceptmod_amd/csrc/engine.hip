@@ -487,6 +487,35 @@ struct smi_engine {
     prof_ev.clear();
   }
 
+  // ---- liveness in NO-GRAD passes (arena 0: pre-roll forwards, frozen-only passes).  Nothing is saved there, so a tensor
+  // is dead once the block after its producer has run.  Allocation inside a block (resnet [+ transformer], sampler conv,
+  // the final norm + conv_out) comes from one of two scratch regions that alternate per block -- block k writes region
+  // k & 1 while it reads block k - 1's output in the other one, and re-starts the region block k - 2 used -- except the
+  // block's OUTPUT when the up path will read it again as a skip connection: that one tensor, and everything allocated
+  // outside blocks (embeddings, grouped projections, conv_in), goes to the persistent bump region.  Arena 0 is then
+  // persistent + 2 x the largest block instead of the sum of all tensors of a pass (SD-XL 1024^2, 16 samples: 80 -> ~10 GB);
+  // the saved pass (arena 1) keeps every tensor: its backward reads them.
+  Arena scr[2];
+  int scr_i = 0;
+  bool in_block = false, persist_next = false;
+  void begin_block() {
+    if (saving || is_vae || is_clip) return;
+    scr_i ^= 1;
+    scr[scr_i].reset();
+    in_block = true;
+  }
+  void end_block() { in_block = false; persist_next = false; }
+  void set_arena0_regions(size_t persistent, size_t scratch) {  // sizes from the dry run (plan)
+    arena[0].cap = persistent;
+    for (int k = 0; k < 2; ++k) {
+      scr[k] = Arena();
+      scr[k].base = arena[0].base + persistent + k * scratch;
+      scr[k].cap = scratch;
+    }
+  }
+  // the next tensor created is the current block's output and must outlive the scratch regions (a skip connection)
+  void keep_next_output() { persist_next = in_block; }
+
   Ten* new_ten(int64_t rows, int cols, int n = 0, int H = 0, int W = 0, size_t elt = 0) {
     tens->emplace_back();
     Ten* t = &tens->back();
@@ -496,15 +525,18 @@ struct smi_engine {
     t->H = H;
     t->W = W;
     t->arow0 = n > 0 ? (int64_t)(n - n_ad) * (rows / n) : 0;
-    t->p = arena_alloc((size_t)rows * cols * (elt ? elt : esz()));
+    const bool keep = persist_next;
+    persist_next = false;
+    t->p = arena_alloc((size_t)rows * cols * (elt ? elt : esz()), keep);
     return t;
   }
   int64_t MA(const Ten* t) const { return t->rows - t->arow0; }  // adapted rows
   char* PA(const Ten* t) const { return (char*)t->p + (size_t)t->arow0 * t->cols * esz(); }
-  void* arena_alloc(size_t bytes) {
-    void* p = cur->alloc(bytes);
-    if (!dry && cur->overflow && !err) {  // never launch a kernel on memory we do not own
-      set_error("workspace arena overflow (%zu > %zu bytes)", cur->off, cur->cap);
+  void* arena_alloc(size_t bytes, bool persistent = false) {
+    Arena* a = (in_block && !persistent) ? &scr[scr_i] : cur;
+    void* p = a->alloc(bytes);
+    if (!dry && a->overflow && !err) {  // never launch a kernel on memory we do not own
+      set_error("workspace arena overflow (%zu > %zu bytes)", a->off, a->cap);
       err = true;
     }
     return p;
@@ -1645,7 +1677,7 @@ struct smi_engine {
     return y;
   }
 
-  Ten* resnet(Ten* x, const Resnet& r, Ten* temb_act) {
+  Ten* resnet(Ten* x, const Resnet& r, Ten* temb_act, bool keep_out = false) {
     Ten* h = groupnorm(x, r.n1, true);
     Ten* t = nullptr;
     int64_t ldt = 0;
@@ -1663,10 +1695,11 @@ struct smi_engine {
     h = conv3x3(h, r.c1, t, nullptr, ldt);
     h = groupnorm(h, r.n2, true);
     Ten* sc = r.has_sc ? linear(x, r.sc) : x;
+    if (keep_out) keep_next_output();  // (conv3x3 creates its output tensor first)
     return conv3x3(h, r.c2, nullptr, sc);
   }
 
-  Ten* transformer(Ten* x, const Transformer& t, Ten* ctx) {
+  Ten* transformer(Ten* x, const Transformer& t, Ten* ctx, bool keep_out = false) {
     const int C = t.C, nb = x->n, Nq = x->H * x->W;
     Ten* h = groupnorm(x, t.norm, false);
     h = linear(h, t.proj_in);
@@ -1689,6 +1722,7 @@ struct smi_engine {
       Ten* gg = linear_geglu(nrm, tb.ff1);
       h = linear(gg, tb.ff2, h);
     }
+    if (keep_out) keep_next_output();  // (linear creates its output tensor first)
     return linear(h, t.proj_out, x);
   }
 
@@ -1958,6 +1992,12 @@ struct smi_engine {
     n_ad = n_adapted;
     cur = &arena[save ? 1 : 0];
     cur->reset();
+    in_block = persist_next = false;
+    if (!save) {
+      scr[0].reset();
+      scr[1].reset();
+      if (dry) scr[0].cap = scr[1].cap = (size_t)-1;
+    }
     if (save) {
       tape.clear();
       tape_valid = false;
@@ -2032,34 +2072,53 @@ struct smi_engine {
       RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * 9 * cfg.in_channels, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     }
 
+    // (begin_block / end_block: scratch-region liveness of the no-grad passes, see new_ten; no-ops in a saved pass)
     std::vector<Ten*> skips;
     skips.push_back(h);
     for (size_t i = 0; i < down.size(); ++i) {
       Level& lv = down[i];
       for (size_t j = 0; j < lv.res.size(); ++j) {
-        h = resnet(h, lv.res[j], temb_act);
-        if (lv.has_att) h = transformer(h, lv.att[j], ctx);
+        begin_block();  // every down-path block output is a skip connection: kept
+        h = resnet(h, lv.res[j], temb_act, !lv.has_att);
+        if (lv.has_att) h = transformer(h, lv.att[j], ctx, true);
+        end_block();
         skips.push_back(h);
       }
       if (lv.has_samp) {
+        begin_block();
+        keep_next_output();
         h = conv3x3(h, lv.samp, nullptr, nullptr);
+        end_block();
         skips.push_back(h);
       }
     }
+    begin_block();
     h = resnet(h, mid.res[0], temb_act);
+    end_block();
+    begin_block();
     h = transformer(h, mid.att[0], ctx);
+    end_block();
+    begin_block();
     h = resnet(h, mid.res[1], temb_act);
+    end_block();
     for (size_t i = 0; i < up.size(); ++i) {
       Level& lv = up[i];
       for (size_t j = 0; j < lv.res.size(); ++j) {
         Ten* sk = skips.back();
         skips.pop_back();
+        begin_block();
         h = concat(h, sk);
         h = resnet(h, lv.res[j], temb_act);
         if (lv.has_att) h = transformer(h, lv.att[j], ctx);
+        end_block();
       }
-      if (lv.has_samp) h = conv3x3(h, lv.samp, nullptr, nullptr);
+      if (lv.has_samp) {
+        begin_block();
+        h = conv3x3(h, lv.samp, nullptr, nullptr);
+        end_block();
+      }
     }
+    begin_block();
     Ten* hn = groupnorm(h, norm_out, true);
 
     // ---- conv_out (MFMA path, fp32 result) + NHWC->NCHW
@@ -2084,6 +2143,7 @@ struct smi_engine {
       RUNP(SMI_PROF_CONV, 2.0 * p.M * p.N * p.K, 0.0, (prof_on && prof_dump ? (next_tag = gemm_tag(p), 0) : 0, launch_gemm(p, stream)));
     }
     RUN(launch_nhwc_to_nchw_f32((const float*)y->p, eps_out, n, cfg.out_channels, HW, stream));
+    end_block();
     y->ng = hn->ng;
     if (saving && y->ng) {
       tape.push_back([=]() {
@@ -2241,7 +2301,7 @@ int setup(smi_engine* e, const smi_unet_config* cfg, const smi_weight* weights, 
 
 // dry run: sizes of the three regions
 int plan(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, int batch, int batch_adapted, int h, int w,
-         int ctx_len, size_t out[3]) {
+         int ctx_len, size_t out[5]) {
   smi_engine e;
   e.dry = true;
   setup(&e, cfg, nullptr, 0, sites, n_sites, batch, batch_adapted, h, w, ctx_len);
@@ -2249,7 +2309,10 @@ int plan(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, in
   if (e.err) return -1;
   out[0] = align_up(e.wpack.peak, 4096);
   e.forward(batch, batch_adapted, nullptr, 0.f, nullptr, nullptr, nullptr, false, nullptr);
-  out[1] = align_up(e.arena[0].peak, 4096);
+  // arena 0 = [persistent | scratch 0 | scratch 1] (no-grad liveness, smi_engine::begin_block)
+  out[3] = align_up(e.arena[0].peak, 4096);
+  out[4] = align_up(std::max(e.scr[0].peak, e.scr[1].peak), 4096);
+  out[1] = out[3] + 2 * out[4];
   e.forward(batch, batch_adapted, nullptr, 0.f, nullptr, nullptr, nullptr, true, nullptr);
   e.backward(nullptr, nullptr, nullptr);
   out[2] = align_up(e.arena[1].peak, 4096);
@@ -2267,7 +2330,7 @@ int smi_workspace_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, 
   if (check_cfg(cfg)) return -1;
   SMI_CHECK(bytes && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
             "bad arguments");
-  size_t r[3];
+  size_t r[5];
   if (plan(cfg, sites, n_sites, batch, batch_adapted, h, w, ctx_len, r)) return -1;
   *bytes = r[0] + r[1] + r[2] + 3 * 4096;
   return 0;
@@ -2279,7 +2342,7 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
   if (check_cfg(cfg)) return -1;
   SMI_CHECK(out && workspace && weights && n_weights > 0 && batch_adapted >= 0 && batch_adapted <= batch,
             "bad arguments");
-  size_t r[3];
+  size_t r[5];
   if (plan(cfg, sites, n_sites, batch, batch_adapted, h, w, ctx_len, r)) return -1;
   SMI_CHECK(r[0] + r[1] + r[2] + 3 * 4096 <= workspace_bytes, "workspace too small: need %zu bytes, got %zu",
             r[0] + r[1] + r[2] + 3 * 4096, workspace_bytes);
@@ -2292,9 +2355,9 @@ int smi_create(const smi_unet_config* cfg, const smi_weight* weights, int n_weig
   e->wpack.base = base;
   e->wpack.cap = r[0];
   e->arena[0].base = base + r[0];
-  e->arena[0].cap = r[1];
   e->arena[1].base = base + r[0] + r[1];
   e->arena[1].cap = r[2];
+  e->set_arena0_regions(r[3], r[4]);
   e->arena_home = base + r[0];
   e->arena_home_bytes = (size_t)((char*)workspace + workspace_bytes - e->arena_home);
   e->build();
@@ -2480,7 +2543,7 @@ int smi_clip_encode(smi_engine* e, int n, const int32_t* ids, const int32_t* eos
 int smi_weights_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int n_sites, size_t* bytes) {
   if (check_cfg(cfg)) return -1;
   SMI_CHECK(bytes != nullptr, "bad arguments");
-  size_t r[3];
+  size_t r[5];
   if (plan(cfg, sites, n_sites, 1, 1, 8, 8, 8, r)) return -1;  // the packed region does not depend on the shape
   *bytes = r[0] + 4096;
   return 0;
@@ -2491,7 +2554,7 @@ int smi_arena_bytes(const smi_unet_config* cfg, const smi_lora_site* sites, int 
   if (check_cfg(cfg)) return -1;
   SMI_CHECK(bytes && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
             "bad arguments");
-  size_t r[3];
+  size_t r[5];
   if (plan(cfg, sites, n_sites, batch, batch_adapted, h, w, ctx_len, r)) return -1;
   *bytes = r[1] + r[2] + 2 * 4096;
   return 0;
@@ -2502,7 +2565,7 @@ int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ct
   SMI_CHECK(e && batch > 0 && batch_adapted >= 0 && batch_adapted <= batch && h > 0 && w > 0 && ctx_len > 0,
             "bad arguments");
   SMI_CHECK(!e->is_vae && !e->is_clip, "smi_replan: only UNet engines re-plan");
-  size_t r[3];
+  size_t r[5];
   if (plan(&e->cfg, e->sites.data(), (int)e->sites.size(), batch, batch_adapted, h, w, ctx_len, r)) return -1;
   char* base = arena ? (char*)align_up((size_t)arena, 4096) : e->arena_home;
   const size_t have = arena ? (size_t)((char*)arena + arena_bytes - base) : e->arena_home_bytes;
@@ -2517,9 +2580,9 @@ int smi_replan(smi_engine* e, int batch, int batch_adapted, int h, int w, int ct
   e->arena[0] = Arena();
   e->arena[1] = Arena();
   e->arena[0].base = base;
-  e->arena[0].cap = r[1];
   e->arena[1].base = base + r[1];
   e->arena[1].cap = r[2];
+  e->set_arena0_regions(r[3], r[4]);
   e->tape.clear();  // the saved activations lived in the old arena
   e->tape_valid = false;
   e->tens_[0].clear();

@@ -559,6 +559,11 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
 //   S = largest power of two <= min(16, 512 / tiles, nk / 4), limited by the scratch the caller provides
 //   (measured 160 / 384 against 256 / 512: SD-1.4 step 24.5 -> 24.2 ms, SD-1.5 B = 4 59.6 -> 59.1, headline 178.9 -> 178.2)
 // SMI_GEMM_SPLITK=0 turns the rule off.
+// NOTE (batch dependence): `tiles` counts the launch's rows, so the SAME sample's product is summed over K in S(batch)
+// slices -- its fp32 summation order changes with the batch it travels in (never from run to run).  Everything that is
+// compared bitwise runs both sides at one batch (batched pass vs separate passes at equal per-launch M of the split
+// shapes, dedup vs full step, tile-selection digests); comparisons across batch sizes (VAE pair vs single, 2 ranks vs 1)
+// carry a tolerance.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 thread_local void* t_scratch = nullptr;

@@ -15,7 +15,8 @@ namespace {
 
 // rows per chunk: at most 64 chunks per sample (the apply kernels re-reduce the chunk partials), at least 16 rows
 // (the 32x32 maps then still give 64 workgroups per sample).  Depends on HW only, so a sample's arithmetic does not
-// depend on the batch it travels in.
+// depend on the batch it travels in (the norms' own arithmetic; the split-K GEMMs' slice count does follow the batch,
+// csrc/gemm.hip).
 // Maps beyond 128 x 128 (the VAE encoder: 1024 x 1024 x 128 channels of ONE image) get 256-row chunks instead -- 64
 // workgroups on 256 CUs ran those at 0.64 TB/s -- and their partials are folded down to 64 slots by gn_fold_kernel
 // before the apply kernels re-reduce them.

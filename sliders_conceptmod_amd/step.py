@@ -26,7 +26,7 @@ class SliderStep:
     def __init__(self, unet, network, scheduler, *, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, max_grad_norm: float = 0.0, cfg_scale: float = 1.0,
                  skip_dead_cfg_half: bool = False, process_group=None, batch_passes: bool = True,
-                 dedup_uncond: bool = False):
+                 dedup_uncond: bool = False, preroll_skip_dead_half: bool = True):
         self.unet, self.network, self.scheduler = unet, network, scheduler
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -44,6 +44,12 @@ class SliderStep:
         # (per-sample arithmetic does not depend on batch composition: tests/test_engine_gpu.py), 8B -> 5B samples
         # per step.  Off by default: the reference runs all of them, so the headline number does too.
         self.dedup = bool(dedup_uncond and batch_passes and not self.skip_dead)
+        # Pre-roll at guidance scale exactly 1 (the SD-XL trainer's default, `train.cfg` = 1.0, T/config_util.py:41,
+        # T/train_lora_xl.py:66,209-231): predict_noise_xl forms u + 1 * (t - u) from the doubled batch, i.e. t up to one fp32
+        # rounding (<= 6e-8 relative) -- the unconditional half only feeds that rounding.  The pre-roll then runs the
+        # conditional half alone (UNet batch B instead of 2B).  Off: the doubled batch at every scale.
+        import os
+        self.preroll_skip_dead_half = bool(preroll_skip_dead_half) and os.environ.get("SMI_PREROLL_FULL") != "1"  # (A/B switch)
         flat = network.flat
         # ONE message per step: [flat fp32 LoRA gradient | loss scalar] -- the loss rides on the
         # gradient's all-reduce
@@ -138,6 +144,16 @@ class SliderStep:
         net.__enter__()
         flat, n_down, mult = net.engine_params()
         net.__exit__(None, None, None)
+        if self.preroll_skip_dead_half and float(guidance_scale) == 1.0:
+            half = {k: v[B:].contiguous() for k, v in c.items()}  # rows [B, 2B) of concat_embeddings: the conditional ones
+            for timestep in self.scheduler.timesteps[start_timesteps:total_timesteps]:
+                x = self.scheduler.scale_model_input(lat, timestep).contiguous()
+                _, _, h, w = x.shape
+                engine = self.unet._ensure_engine(B, h, w, half["ctx"].shape[1])
+                pred = engine.forward(x, float(timestep), half["ctx"], half.get("text_embeds"), half.get("time_ids"),
+                                      flat[:n_down], flat[n_down:], mult, False)
+                lat = self.scheduler.step(pred, timestep, lat).prev_sample
+            return lat
         for timestep in self.scheduler.timesteps[start_timesteps:total_timesteps]:
             x = self.scheduler.scale_model_input(torch.cat([lat] * 2), timestep).contiguous()
             _, _, h, w = x.shape

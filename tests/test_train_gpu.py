@@ -455,12 +455,15 @@ def test_cli_main_runs_the_shipped_c3lier_config_end_to_end(tmp_path, monkeypatc
     assert any(float(v.float().abs().max()) > 0 for v in conv_up), "conv adaptors did not train"
 
 
-@pytest.mark.parametrize("sched_name,model", [("euler_a", "tiny_sdxl"), ("ddim", "tiny_sd1x")])
-def test_native_preroll_matches_the_oracle(sched_name, model):
+@pytest.mark.parametrize("sched_name,model,gscale", [("euler_a", "tiny_sdxl", 3.0), ("ddim", "tiny_sd1x", 3.0),
+                                                     ("euler_a", "tiny_sdxl", 1.0)])
+def test_native_preroll_matches_the_oracle(sched_name, model, gscale):
     """Row f-1: the on-device pre-roll (SliderStep.preroll: engine forward, smi_cfg_combine, smi_sched_step per denoising
     step, adaptor ON, CFG scale 3) against the ORACLE's diffusion(_xl) (T/train_util.py:306-327, 677-708) on the CPU --
     an independent implementation, not the same engine.  Euler-ancestral noise is drawn on the host from the same seed
-    on both sides."""
+    on both sides.  gscale 1.0 is the SD-XL trainer's default `train.cfg`: the oracle runs the reference's doubled batch
+    (u + 1 (t - u)), the product the conditional half alone (SliderStep.preroll_skip_dead_half) and, for comparison, the
+    doubled batch too."""
     import sliders_conceptmod_amd.model_util as MU
     from sliders_conceptmod_amd.step import SliderStep
     from oracle import sched_ref as S, slider_ref as R
@@ -484,16 +487,24 @@ def test_native_preroll_matches_the_oracle(sched_name, model):
     with torch.no_grad(), onet:
         if xl:
             ref = R.diffusion_xl(ou, osch, lat0, te, R.concat_embeddings(pooled["unconditional"], pooled["target"], 2),
-                                 R.concat_embeddings(tid, tid, 2), guidance_scale=3.0, total_timesteps=5)
+                                 R.concat_embeddings(tid, tid, 2), guidance_scale=gscale, total_timesteps=5)
         else:
-            ref = R.diffusion(ou, osch, lat0, te, total_timesteps=5, guidance_scale=3.0)
+            ref = R.diffusion(ou, osch, lat0, te, total_timesteps=5, guidance_scale=gscale)
     step = SliderStep(pu, pnet, psch)
     cond = step.make_conditioning(emb, 2, pooled, tid)
     torch.manual_seed(11)
-    got = step.preroll(lat0.cuda(), cond, 5, 3.0)
+    got = step.preroll(lat0.cuda(), cond, 5, gscale)
     e = float((got.cpu() - ref).norm() / ref.norm())
-    print(f"{model} {sched_name}: 5-step pre-roll vs oracle rel err {e:.2e}")
+    print(f"{model} {sched_name} g={gscale}: 5-step pre-roll vs oracle rel err {e:.2e}")
     assert e < 3e-3, e
+    if gscale == 1.0:  # the doubled batch at scale 1 lands on the same latents (to the engine's own rounding noise)
+        full = SliderStep(pu, pnet, psch, preroll_skip_dead_half=False)
+        torch.manual_seed(11)
+        got2 = full.preroll(lat0.cuda(), cond, 5, gscale)
+        e2 = float((got2.cpu() - ref).norm() / ref.norm())
+        d = float((got2 - got).norm() / got.norm())
+        print(f"   doubled batch: vs oracle {e2:.2e}; conditional-half-only vs doubled {d:.2e}")
+        assert e2 < 3e-3 and d < 3e-3, (e2, d)
 
 
 def test_xl_trainer_peft_type_dora(tmp_path):

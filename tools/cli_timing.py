@@ -1,7 +1,9 @@
 """End-to-end timing of the text-slider CLI code path at the headline shape: `train_lora_xl.train` --
 SD-XL architecture (synthetic weights, synthetic://sdxl), 1024 x 1024, batch_size 2, rank 4, Euler-a, 12 denoising steps --
-20 iterations INCLUDING the reference's stochastic pre-roll (timesteps_to ~ U{1..11} forwards per step), with and without
---fused_step.  Prints one JSON line per mode: iterations/s over the iterations after the first two (engine set-up, tile
+20 iterations INCLUDING the reference's stochastic pre-roll (timesteps_to ~ U{1..11} forwards per step) in three modes: the
+CLI default (round 4: fused step, each distinct frozen sample once, conditional-half pre-roll at train.cfg = 1), round 3's
+`--fused_step` (full 8B-sample step, doubled-batch pre-roll) and `--no_fused_step` (the reference-style autograd loop).
+Prints one JSON line per mode: iterations/s over the iterations after the first two (engine set-up, tile
 tuning), and the mean number of pre-roll forwards the RNG happened to draw."""
 import json, os, sys, time
 import torch
@@ -11,7 +13,9 @@ import sliders_conceptmod_amd.prompt_util as PRU
 from sliders_conceptmod_amd.train_lora_xl import train
 
 iters = int(os.environ.get("SMI_CLI_ITERS", "20"))
-for fused in (True, False):
+for mode, fused, dedup, full_pre in (("default", None, True, False), ("round-3 --fused_step", True, False, True),
+                                     ("--no_fused_step", False, False, True)):
+    os.environ["SMI_PREROLL_FULL"] = "1" if full_pre else "0"
     cfg = CU.RootConfig(
         prompts_file="unused", pretrained_model=CU.PretrainedModelConfig(name_or_path="synthetic://sdxl"),
         network=CU.NetworkConfig(type="lierla", rank=4, alpha=1.0, training_method="noxattn"),
@@ -29,8 +33,10 @@ for fused in (True, False):
         torch.cuda.synchronize()
         stamps.append(time.perf_counter())
 
-    train(cfg, prompts, torch.device("cuda:0"), on_step_complete=tick, rank=4, save_file=False, fused_step=fused)
+    train(cfg, prompts, torch.device("cuda:0"), on_step_complete=tick, rank=4, save_file=False, fused_step=fused,
+          dedup_uncond=dedup)
     dt = stamps[-1] - stamps[1]
     n = len(stamps) - 2
-    print(json.dumps({"cli": "train_lora_xl.train", "fused_step": fused, "shape": "SD-XL 1024^2, batch_size 2, rank 4, 12-step "
+    print(json.dumps({"cli": "train_lora_xl.train", "mode": mode, "fused_step": fused is not False, "dedup_uncond": dedup,
+                      "preroll": "doubled batch" if full_pre else "conditional half (train.cfg = 1)", "shape": "SD-XL 1024^2, batch_size 2, rank 4, 12-step "
                       "Euler-a pre-roll", "iterations_timed": n, "it_per_s": n / dt, "s_per_it": dt / n}), flush=True)
