@@ -658,6 +658,9 @@ def main():
                                    "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] else None,
                                    "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] else None}
                                for k, v in prof.items()},
+            "kernel_classes_note": "HIP events around every launch of ONE separately profiled step: the events add about 2 % "
+                                   "(the classes sum to more than ms_per_step); the rocprofv3 kernel trace cut into "
+                                   "steady-state steps (profiles/r*_trace_steps_*.json) is the better per-class source",
         }
         # weak scaling: a unit is one 4-pass step on one per-GPU batch B; all ranks together process world*steps units
         if world == 1 and not args.no_cpu_baseline:

@@ -416,6 +416,18 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
           for (int b = 0; b < 4; ++b)
             if (b < nblk) au[nip][b] = p.lora_up[(int64_t)(ncol + 4 * nip) * p.lora_r + 4 * b + fq];
       }
+      // the residual rows of all four m-fragments of the pair are requested up front: written inside the mi loop each load
+      // sat in its own basic block (the epilogue terms are run-time switches) with its wait right behind it -- 20 dependent
+      // round trips per lane and tile, the whole chip in them at once in the one-round N = 1280 launches
+      // (not in the plain conv mode: its tap masks leave no registers for the four rows -- 5 spills -- and its few
+      // launches with a residual are multi-round, where the next tile's prefetch already runs under the epilogue)
+      constexpr bool RES_AHEAD = !CONV;
+      Pack8<T> rbuf[4];
+      if (RES_AHEAD && p.res) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          rbuf[mi].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (int64_t)row_of(mi) * p.ldr + n);
+      }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int m = row_of(mi);
@@ -487,10 +499,10 @@ __global__ __launch_bounds__(512) void gemm_5ph_kernel(GemmParams p) {
           }
         }
         if (p.res) {
-          Pack8<T> b;
-          b.u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n);
+          if constexpr (!RES_AHEAD)
+            rbuf[mi].u = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) vv[j] += to_f(b.e[j]);
+          for (int j = 0; j < 8; ++j) vv[j] += to_f(rbuf[mi].e[j]);
         }
         if (p.out_f32) {
           float* op = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
