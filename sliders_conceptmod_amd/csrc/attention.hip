@@ -173,7 +173,9 @@ __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r 
 // log2-domain exponents relative to the reference: p = exp2(acc), no multiply, no subtraction -- 32 of the ~150 VALU
 // instructions per key tile of a loop whose busiest resource is the SIMD's vector issue port (rocprofv3: VALU 60 %,
 // MFMA 47 % busy).
-template <typename T, int DP, int NSD, bool PRE>
+// DEEP (kept as an A/B switch, SMI_ATTN_FWD_DEEP=1; measured: no effect): K / V tiles requested TWO tiles
+// ahead through two alternating register sets (the loop body is instantiated twice, so the sets are named, not indexed).
+template <typename T, int DP, int NSD, bool PRE, bool DEEP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   using S = Stage<T, DP>;
   constexpr int NS = DP / 16, NB = DP / 32;
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int ntiles = (p.Nk + TK - 1) / TK;
   // K/V tiles are fetched one tile ahead into registers: the global-load latency hides under the MFMAs / softmax
   u32x4 rk[S::NIT], rv[S::NIT];
+  u32x4 rk2[DEEP ? S::NIT : 1], rv2[DEEP ? S::NIT : 1];  // DEEP: the second register set (tile kt + 2)
   S::load(rk, rK, 0, p.Nk, p.ldk, col0, p.D, tid);
   S::load(rv, rV, 0, p.Nk, p.ldv, col0, p.D, tid);
   S::store_nat(rk, Ks2[0], tid);
@@ -235,17 +238,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     S::load(rk, rK, TK, p.Nk, p.ldk, col0, p.D, tid);
     S::load(rv, rV, TK, p.Nk, p.ldv, col0, p.D, tid);
   }
+  if constexpr (DEEP) {
+    if (ntiles > 2) {
+      S::load(rk2, rK, 2 * TK, p.Nk, p.ldk, col0, p.D, tid);
+      S::load(rv2, rV, 2 * TK, p.Nk, p.ldv, col0, p.D, tid);
+    }
+  }
   __syncthreads();
-  for (int kt = 0; kt < ntiles; ++kt) {
+  constexpr int AHEAD = DEEP ? 3 : 2;  // the set a tile body frees is refilled with tile kt + AHEAD
+  // one key tile; (xk, xv) = the register set that holds tile kt + 1 on entry
+  auto tile_body = [&](int kt, auto& xk, auto& xv) {
     const int k0 = kt * TK;
     const T* Ks = Ks2[kt & 1];
     const T* Vs = Vs2[kt & 1];
-    if (kt + 1 < ntiles) {  // tile kt + 1 (in registers since the previous iteration) into the other stage, kt + 2 on its way
-      S::store_nat(rk, Ks2[(kt + 1) & 1], tid);
-      S::store_ld(rv, Vs2[(kt + 1) & 1], S::LDV, tid);
-      if (kt + 2 < ntiles) {
-        S::load(rk, rK, k0 + 2 * TK, p.Nk, p.ldk, col0, p.D, tid);
-        S::load(rv, rV, k0 + 2 * TK, p.Nk, p.ldv, col0, p.D, tid);
+    if (kt + 1 < ntiles) {  // tile kt + 1 (in registers since an earlier iteration) into the other stage, kt + AHEAD on its way
+      S::store_nat(xk, Ks2[(kt + 1) & 1], tid);
+      S::store_ld(xv, Vs2[(kt + 1) & 1], S::LDV, tid);
+      if (kt + AHEAD < ntiles) {
+        S::load(xk, rK, k0 + AHEAD * TK, p.Nk, p.ldk, col0, p.D, tid);
+        S::load(xv, rV, k0 + AHEAD * TK, p.Nk, p.ldv, col0, p.D, tid);
       }
     }
 
@@ -361,6 +372,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         l4 = Sum4<T>::add8(pf, l4);
       }
     __syncthreads();  // every wave is done with stage kt & 1, and stage (kt + 1) & 1 is complete
+  };
+  if constexpr (DEEP) {
+    for (int kt = 0; kt < ntiles; kt += 2) {
+      tile_body(kt, rk, rv);
+      if (kt + 1 < ntiles) tile_body(kt + 1, rk2, rv2);
+    }
+  } else {
+    for (int kt = 0; kt < ntiles; ++kt) tile_body(kt, rk, rv);
   }
 
   const float l_tot = halves_sum(l4[0]);
@@ -1232,7 +1251,10 @@ int fwd_t(const AttnParams& p, hipStream_t st) {
       return 0;
     }
   }
-  if (nsd == NS) {
+  static const bool deep = []() { const char* e = getenv("SMI_ATTN_FWD_DEEP"); return e && e[0] == '1'; }();
+  if (nsd == NS && deep && DP == 64) {
+    if constexpr (DP == 64) hipLaunchKernelGGL((attn_fwd_kernel<T, DP, NS, false, true>), grid, dim3(256), 0, st, p);
+  } else if (nsd == NS) {
     hipLaunchKernelGGL((attn_fwd_kernel<T, DP, NS, false>), grid, dim3(256), 0, st, p);
   } else if (ALT > 0 && nsd == ALT) {
     hipLaunchKernelGGL((attn_fwd_kernel<T, DP, (ALT > 0 ? ALT : NS), false>), grid, dim3(256), 0, st, p);
