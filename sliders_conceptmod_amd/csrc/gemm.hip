@@ -297,8 +297,12 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const T* __restrict_
 // (bias, row vector, rank-r delta as the canonical fmaf chain of smi_common.h, residual), one rounding at the store.
 // One thread = 4 consecutive columns of one row.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(GemmParams p, const float* __restrict__ slab, int nsplit) {
+// NS > 0: the slice count as a compile-time constant -- with the run-time count hipcc keeps the slab loop rolled, one
+// dependent L2 round trip per slice (6.9 us per launch, 7236 launches in a 22-step SD-1.4 run); unrolled, all slices of an
+// element are in flight at once.  The sum still runs over ascending slices: same bits.
+template <typename T, int NS>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(GemmParams p, const float* __restrict__ slab, int nsplit_rt) {
+  const int nsplit = NS > 0 ? NS : nsplit_rt;
   const int n4 = p.N >> 2;
   const int64_t total = (int64_t)p.M * n4;
   const int64_t plane = (int64_t)p.M * p.N;
@@ -307,10 +311,20 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmParams p, const 
     const int n = (int)(idx - (int64_t)m * n4) * 4;
     const float* sp = slab + (int64_t)m * p.N + n;
     f32x4 v = *reinterpret_cast<const f32x4*>(sp);
-    for (int s = 1; s < nsplit; ++s) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(sp + s * plane);
+    if constexpr (NS > 0) {
+      f32x4 w[NS > 1 ? NS - 1 : 1];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += w[j];
+      for (int s = 1; s < NS; ++s) w[s - 1] = *reinterpret_cast<const f32x4*>(sp + s * plane);
+#pragma unroll
+      for (int s = 1; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += w[s - 1][j];
+    } else {
+      for (int s = 1; s < nsplit; ++s) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sp + s * plane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += w[j];
+      }
     }
     if (p.bias) {
       Pack4<T> b;
@@ -603,10 +617,18 @@ int launch_splitk(const GemmParams& p, int S, hipStream_t stream) {
   if (launch_gemm2(q, wg64 <= 512 ? 7 : 5, stream) != 0) return -1;
   const int64_t total = (int64_t)p.M * (p.N / 4);
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  if (p.dtype == DT_F16)
-    hipLaunchKernelGGL(splitk_finish_kernel<f16>, dim3(grid), dim3(256), 0, stream, p, (const float*)t_scratch, S);
-  else
-    hipLaunchKernelGGL(splitk_finish_kernel<bf16>, dim3(grid), dim3(256), 0, stream, p, (const float*)t_scratch, S);
+#define FIN(TT_, NS_) hipLaunchKernelGGL((splitk_finish_kernel<TT_, NS_>), dim3(grid), dim3(256), 0, stream, p, (const float*)t_scratch, S)
+#define FIN_T(TT_)                   \
+  do {                               \
+    if (S == 2) FIN(TT_, 2);         \
+    else if (S == 4) FIN(TT_, 4);    \
+    else if (S == 8) FIN(TT_, 8);    \
+    else if (S == 16) FIN(TT_, 16);  \
+    else FIN(TT_, 0);                \
+  } while (0)
+  if (p.dtype == DT_F16) FIN_T(f16); else FIN_T(bf16);
+#undef FIN_T
+#undef FIN
   SMI_HIP(hipGetLastError());
   return 0;
 }

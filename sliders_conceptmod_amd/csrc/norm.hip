@@ -8,6 +8,8 @@
 //                     of chunk 0 also stores mean / rstd and the per-(n,c) affine a, b for the backward
 // GroupNorm backward: z = x*a+b, dz = dy*silu'(z);  S1 = sum dz*gamma, S2 = sum dz*(z-beta)  per (n,g)
 //                     dx = a*dz + c2*x + c3   with  c2 = -r^2*S2/cnt,  c3 = -r*S1/cnt - c2*mu
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace smi {
@@ -275,6 +277,123 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// GroupNorm forward in ONE launch for maps whose (sample, group) slice fits LDS (SD-1.x at batch 1-4, every pre-roll, the
+// deeper levels of SD-XL): workgroup (g, n) reads its HW x (C / G) slice once in 4-byte pieces (two channels; the group
+// width is even everywhere), keeps it in LDS, reduces sum / sum of squares in a fixed order, applies the affine (+ SiLU)
+// from LDS and writes.  The two-kernel form costs such maps two launches of 8-16 us that are pure latency (SD-1.4: 12 % of
+// all kernel time is GroupNorm, ~7500 launches in a 22-step run).  Statistics, affine and mean / rstd are stored exactly
+// as the two-kernel form stores them (the backward reads them); the selection depends on (HW, C, G) only, so a sample's
+// arithmetic does not depend on its batch.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                           const T* __restrict__ beta, T* __restrict__ y,
+                                                           float* __restrict__ aa, float* __restrict__ bb,
+                                                           float* __restrict__ mean_rstd, int HW, int C, int G, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gn_smem[];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G, dpr = cpg >> 1, total = HW * dpr;  // dpr: 4-byte pieces per row of the slice
+  uint32_t* tile = reinterpret_cast<uint32_t*>(gn_smem);
+  float* fl = reinterpret_cast<float*>(gn_smem + (((size_t)total * 4 + 15) & ~(size_t)15));
+  float* red = fl;             // [4][2] per-wave partial sums
+  float* af = fl + 8;          // [cpg]
+  float* bf = af + cpg;        // [cpg]
+  const T* xg = x + (int64_t)n * HW * C + (int64_t)g * cpg;
+  T* yg = y + (int64_t)n * HW * C + (int64_t)g * cpg;
+  const int drow = 256 / dpr, dd = 256 - drow * dpr;  // idx += 256  <=>  (row, d) += (drow, dd) with carry
+  union W2 {
+    uint32_t u;
+    T e[2];
+  };
+  float s = 0.f, sq = 0.f;
+  {
+    int row = tid / dpr, d = tid - row * dpr;
+    for (int idx = tid; idx < total; idx += 256) {
+      W2 w;
+      w.u = *reinterpret_cast<const uint32_t*>(xg + (int64_t)row * C + 2 * d);
+      tile[idx] = w.u;
+      const float v0 = to_f(w.e[0]), v1 = to_f(w.e[1]);
+      s += v0 + v1;
+      sq += v0 * v0 + v1 * v1;
+      d += dd;
+      row += drow;
+      if (d >= dpr) {
+        d -= dpr;
+        ++row;
+      }
+    }
+  }
+  s = wave_sum(s);
+  sq = wave_sum(sq);
+  if ((tid & 63) == 0) {
+    red[(tid >> 6) * 2] = s;
+    red[(tid >> 6) * 2 + 1] = sq;
+  }
+  __syncthreads();
+  const float cnt = (float)HW * (float)cpg;
+  const float ts = (red[0] + red[2]) + (red[4] + red[6]), tq = (red[1] + red[3]) + (red[5] + red[7]);
+  const float mean = ts / cnt;
+  const float var = fmaxf(tq / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  if (tid == 0) {
+    mean_rstd[((int64_t)n * G + g) * 2] = mean;
+    mean_rstd[((int64_t)n * G + g) * 2 + 1] = rstd;
+  }
+  if (tid < cpg) {
+    const int c = g * cpg + tid;
+    const float a = rstd * to_f(gamma[c]);
+    const float b = to_f(beta[c]) - mean * a;
+    af[tid] = a;
+    bf[tid] = b;
+    aa[(int64_t)n * C + c] = a;  // the backward reads the affine back
+    bb[(int64_t)n * C + c] = b;
+  }
+  __syncthreads();
+  {
+    int row = tid / dpr, d = tid - row * dpr;
+    for (int idx = tid; idx < total; idx += 256) {
+      W2 w, o;
+      w.u = tile[idx];
+      float z0 = to_f(w.e[0]) * af[2 * d] + bf[2 * d];
+      float z1 = to_f(w.e[1]) * af[2 * d + 1] + bf[2 * d + 1];
+      if (SILU) {
+        z0 = silu_f(z0);
+        z1 = silu_f(z1);
+      }
+      o.e[0] = from_f<T>(z0);
+      o.e[1] = from_f<T>(z1);
+      *reinterpret_cast<uint32_t*>(yg + (int64_t)row * C + 2 * d) = o.u;
+      d += dd;
+      row += drow;
+      if (d >= dpr) {
+        d -= dpr;
+        ++row;
+      }
+    }
+  }
+}
+// largest (sample, group) slice the one-launch form takes, in bytes (SMI_GN_FUSED_MAX; 0 = never)
+static size_t gn_fused_max() {
+  static const size_t v = []() {
+    const char* e = getenv("SMI_GN_FUSED_MAX");
+    return e ? (size_t)atoll(e) : (size_t)98304;
+  }();
+  return v;
+}
+// Measured (tools/bench_norm.py, SMI_GN_FUSED_MAX = 0 | 98304): the one-launch form wins where the map is a handful of rows
+// -- 2 x 256 x 1280: 16.0 -> 8.5 us, 2 x 256 x 2560: 27.9 -> 13.7, 2 x 64 x 1280: 15.7 -> 4.8, 8 x 64 x 2560: 27.6 -> 5.7 -- and
+// loses from 1024 rows on (2 x 1024 x 1280: 18 -> 34 us, 2 x 4096 x 320: 17 -> 42: one workgroup then streams 80 KB in 4-byte
+// pieces): taken for maps of at most 256 pixels (the 16 x 16 and 8 x 8 levels of SD-1.x, the deepest level of small SD-XL
+// latents).
+static bool gn_fused_ok(int HW, int C, int G) {
+  static const int max_hw = []() { const char* e = getenv("SMI_GN_FUSED_HW"); return e ? atoi(e) : 256; }();
+  const int cpg = C / G;
+  const size_t slice = (size_t)HW * cpg * 2;
+  return HW <= max_hw && (cpg & 1) == 0 && cpg >= 2 && cpg <= 256 && slice <= gn_fused_max() &&
+         slice + 16 + (8 + 2 * cpg) * 4 <= 160 * 1024;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LayerNorm: a wave owns R consecutive rows (C <= 8*64*LN_MAXV); NV = vectors of 8 elements per lane is a template
 // parameter, so a 1280-wide row is 3 loads per lane with no dead registers; the loads of all R rows are issued up front
 // and their reductions interleave.  The wave reduction runs on DPP within 16-lane rows (quad swaps, half mirror, mirror)
@@ -484,6 +603,27 @@ inline const float* gn_fold(float* partial, int Nb, int nchunk, int G, hipStream
 template <typename T>
 int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* ab, float* mean_rstd, float* partial,
              int Nb, int HW, int C, int G, float eps, int silu, hipStream_t st) {
+  if (gn_fused_ok(HW, C, G)) {
+    const int cpg = C / G;
+    const size_t smf = (((size_t)HW * (cpg >> 1) * 4 + 15) & ~(size_t)15) + (8 + 2 * cpg) * sizeof(float);
+    if (silu) {
+      if (smf > 65536) {
+        static DynLdsOnce once;
+        if (int rc = once.set((const void*)gn_fused_fwd_kernel<T, true>, (int)(160 * 1024))) return rc;
+      }
+      hipLaunchKernelGGL((gn_fused_fwd_kernel<T, true>), dim3(G, Nb), dim3(256), smf, st, (const T*)x, (const T*)gamma,
+                         (const T*)beta, (T*)y, ab, ab + (size_t)Nb * C, mean_rstd, HW, C, G, eps);
+    } else {
+      if (smf > 65536) {
+        static DynLdsOnce once;
+        if (int rc = once.set((const void*)gn_fused_fwd_kernel<T, false>, (int)(160 * 1024))) return rc;
+      }
+      hipLaunchKernelGGL((gn_fused_fwd_kernel<T, false>), dim3(G, Nb), dim3(256), smf, st, (const T*)x, (const T*)gamma,
+                         (const T*)beta, (T*)y, ab, ab + (size_t)Nb * C, mean_rstd, HW, C, G, eps);
+    }
+    SMI_HIP(hipGetLastError());
+    return 0;
+  }
   const int nchunk = gn_num_chunks(HW);
   const GnGeom gg = gn_geom(C);
   const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);

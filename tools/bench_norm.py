@@ -30,7 +30,11 @@ def main():
     print("GroupNorm+SiLU (32 groups): Nb HW C | fwd us (TB/s) | fwd+bwd us | bwd TB/s")
     for nb, hw, c in [(16, 16384, 320), (16, 16384, 640), (16, 16384, 960), (16, 4096, 640), (16, 4096, 1280),
                       (16, 4096, 1920), (16, 1024, 1280), (16, 1024, 2560), (4, 16384, 320), (4, 16384, 960),
-                      (4, 4096, 640), (4, 4096, 1920), (4, 1024, 1280), (4, 1024, 2560)]:
+                      (4, 4096, 640), (4, 4096, 1920), (4, 1024, 1280), (4, 1024, 2560),
+                      # SD-1.x at UNet batch 2 / 8 (B = 1 pre-roll / step), the small maps of every pre-roll:
+                      (2, 4096, 320), (2, 1024, 640), (2, 1024, 1280), (2, 1024, 1920), (2, 256, 1280), (2, 256, 2560),
+                      (2, 64, 1280), (8, 4096, 320), (8, 1024, 640), (8, 1024, 1280), (8, 256, 1280), (8, 256, 2560),
+                      (8, 64, 2560)]:
         x = torch.randn(nb, hw, c, device="cuda", dtype=dt)
         dy = torch.randn_like(x)
         y, dx = torch.empty_like(x), torch.empty_like(x)
