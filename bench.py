@@ -586,9 +586,9 @@ def main():
         pre_step.preroll(denoised, cond, n_pre, 1.0)
         torch.cuda.synchronize()
         preroll_cfg1_ms = (time.perf_counter() - t0) * 1e3
-    if os.environ.get("SMI_BENCH_PROFILE_PREROLL") == "1":  # per-shape table of ONE pre-roll forward (with SMI_PROF_DUMP=1)
-        unet._engine.profile_enable(True)
-        pre_step.preroll(denoised, cond, 1, 3.0)
+    if os.environ.get("SMI_BENCH_PROFILE_PREROLL") in ("1", "g1"):  # per-shape table of ONE pre-roll forward (with SMI_PROF_DUMP=1)
+        unet._engine.profile_enable(True)                             # "g1": at guidance 1 (the conditional half alone)
+        pre_step.preroll(denoised, cond, 1, 1.0 if os.environ["SMI_BENCH_PROFILE_PREROLL"] == "g1" else 3.0)
         pp = unet._engine.profile_read()
         unet._engine.profile_enable(False)
         if rank == 0:

@@ -19,6 +19,7 @@
 #include <unordered_map>
 
 #include "kernels.h"
+#include <type_traits>
 
 #include <mutex>
 
@@ -339,14 +340,58 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmParams p, const 
       for (int j = 0; j < 4; ++j) v[j] += to_f(b.e[j]);
     }
     if (p.lora_r > 0 && m >= p.lora_row0) {
-      const float* xrow0 = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa;
+      // (lora_seg is a multiple of 4: the thread's four columns share one segment, hence one xa row)
+      const float* xr = p.lora_xa + (int64_t)(m - p.lora_row0) * p.ld_xa + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
+      const float* up0 = p.lora_up + (int64_t)n * p.up_sn;
+      // ranks 4 / 8 unrolled: every operand of the delta is requested before the first fmaf (the rolled loop with its
+      // run-time strides made 2 r dependent round trips per column: +18 us on a 2048 x 1280 launch).  Same canonical chain.
+      auto delta = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        float x[R], u[4][R];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* xr = xrow0 + (p.lora_seg ? ((n + j) / p.lora_seg) * p.lora_r : 0);
-        const float* up = p.lora_up + (int64_t)(n + j) * p.up_sn;
-        float d = 0.f;
-        for (int r = 0; r < p.lora_r; ++r) d = __builtin_fmaf(xr[r], up[r * p.up_sq], d);
-        v[j] = __builtin_fmaf(d, p.lora_scale, v[j]);
+        for (int r = 0; r < R; ++r) x[r] = xr[r];
+        const bool al = (reinterpret_cast<uintptr_t>(p.lora_up) & 15) == 0;
+        if (al && p.up_sq == 1 && p.up_sn == R) {  // [N, r] rows: 16-byte pieces (a lane's dword loads at a 4 r-byte
+          // stride touch 64 lines per wave-instruction: 16 of them per thread made the delta cost 17 of the finish's 24 us)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < R / 4; ++q) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(up0 + j * R + q * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[j][q * 4 + e] = t[e];
+            }
+        } else if (al && p.up_sn == 1 && (p.up_sq & 3) == 0) {  // [r, K] read transposed: four columns of one rank row
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(up0 + (int64_t)r * p.up_sq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j][r] = t[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[j][r] = up0[(int64_t)j * p.up_sn + (int64_t)r * p.up_sq];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float d = 0.f;
+#pragma unroll
+          for (int r = 0; r < R; ++r) d = __builtin_fmaf(x[r], u[j][r], d);
+          v[j] = __builtin_fmaf(d, p.lora_scale, v[j]);
+        }
+      };
+      if (p.lora_r == 4) delta(std::integral_constant<int, 4>{});
+      else if (p.lora_r == 8) delta(std::integral_constant<int, 8>{});
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* up = up0 + (int64_t)j * p.up_sn;
+          float d = 0.f;
+          for (int r = 0; r < p.lora_r; ++r) d = __builtin_fmaf(xr[r], up[r * p.up_sq], d);
+          v[j] = __builtin_fmaf(d, p.lora_scale, v[j]);
+        }
       }
     }
     if (p.res) {
@@ -569,7 +614,7 @@ int tuned_choice(const GemmParams& p, hipStream_t stream) {
 // the rule sits in front of every generation override: each slice accumulates its K-tiles in ascending order on the
 // gemm2 kernels (bit-identical among themselves) and one finish kernel adds the slices in order and applies the epilogue,
 // so the SMI_GEMM overrides still agree bit for bit with the default selection.
-//   tiles = 128 x 128 output tiles, nk = 64-deep K-tiles:  tiles <= 256, nk >= 16
+//   tiles = 128 x 128 output tiles, nk = 64-deep K-tiles:  tiles <= 256, nk >= 16 (nk >= 32 from 96 tiles on: round 4, below)
 //   S = largest power of two <= min(16, 512 / tiles, nk / 4), limited by the scratch the caller provides
 //   (measured 160 / 384 against 256 / 512: SD-1.4 step 24.5 -> 24.2 ms, SD-1.5 B = 4 59.6 -> 59.1, headline 178.9 -> 178.2)
 // SMI_GEMM_SPLITK=0 turns the rule off.
@@ -589,6 +634,15 @@ int splitk_slices(const GemmParams& p) {
   const int nk = cdiv(p.K, 64);
   static const int max_tiles = []() { const char* e = getenv("SMI_SPLITK_MAXTILES"); return e ? atoi(e) : 256; }();
   if (tiles > max_tiles || nk < 16) return 1;
+  // K = 1024-1984 (16-31 K-tiles) splits only while the un-split launch's 64-row tiles would leave the chip under-filled
+  // (fewer than 96 of the 128 x 128 tiles, i.e. fewer than 192 workgroups).  Measured inside the pre-roll passes
+  // (SMI_BENCH_PROFILE_PREROLL, HIP events): 2048 x 1280 x 1280 (160 tiles) 26.1 us un-split vs 29.5 split in two,
+  // 512 x 5120 x 1280 (160) 24.5 vs 28.5, 8192 x 320 x 1280 (192) 28.4 vs 30.2, 512 x 3840 x 1280 (120) 26.3 vs 27.6 -- but
+  // 512 x 1280 x 1280 (40) 23-25 vs 18-20, 128 x 3840 x 1280 (30) 25.9 vs 17.3.  (Back to back with hot operands the
+  // un-split form wins at 40 tiles too, tools/bench_splitk.py: cold weights want the workgroups.)
+  static const int few_tiles = []() { const char* e = getenv("SMI_SPLITK_FEWTILES"); return e ? atoi(e) : 95; }();
+  static const int long_k = []() { const char* e = getenv("SMI_SPLITK_LONGK"); return e ? atoi(e) : 32; }();
+  if (nk < long_k && tiles > few_tiles) return 1;
   int64_t lim = 16;
   const int64_t budget = 512;  // workgroup-tiles per launch after the split (two per CU)
   if (budget / tiles < lim) lim = budget / tiles;
@@ -599,7 +653,7 @@ int splitk_slices(const GemmParams& p) {
   while (2 * s <= lim) s *= 2;
   return s;
 }
-int launch_splitk(const GemmParams& p, int S, hipStream_t stream) {
+int launch_splitk(const GemmParams& p, int S, hipStream_t stream, int variant = -1) {
   if (p.conv) {
     SMI_CHECK(p.K == 9 * p.Cin && p.M == p.Nb * p.Hout * p.Wout && (p.stride == 1 || p.stride == 2),
               "conv: inconsistent geometry");
@@ -612,9 +666,13 @@ int launch_splitk(const GemmParams& p, int S, hipStream_t stream) {
   q.lora_r = 0;
   q.lora_xa = q.lora_up = nullptr;
   q.ksplit = S;
-  // 64 x 128 tiles (4 waves) while that still leaves CUs idle, else the 128 x 128 eight-wave tile
+  // 64 x 128 tiles (4 waves) while that still leaves CUs idle, else the 128 x 128 eight-wave tile.  (SMI_SPLITK_T160=1: the
+  // 128 x 160 eight-wave tile where N allows -- back to back it wins, 2048 x 1280 x 5120 in two slices 46.5 vs 47.3 us, inside
+  // a pass it loses: 61.4 vs 58.2 us there, SD-1.4 pre-roll 174.0 vs 172.3 ms.)
   const int64_t wg64 = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * S;
-  if (launch_gemm2(q, wg64 <= 512 ? 7 : 5, stream) != 0) return -1;
+  static const bool t160 = []() { const char* e = getenv("SMI_SPLITK_T160"); return e && e[0] == '1'; }();
+  const int v = wg64 <= 512 ? 7 : (t160 && p.N % 160 == 0 ? 10 : 5);
+  if (launch_gemm2(q, variant >= 0 ? variant : v, stream) != 0) return -1;
   const int64_t total = (int64_t)p.M * (p.N / 4);
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
 #define FIN(TT_, NS_) hipLaunchKernelGGL((splitk_finish_kernel<TT_, NS_>), dim3(grid), dim3(256), 0, stream, p, (const float*)t_scratch, S)
@@ -642,6 +700,15 @@ void set_gemm_scratch(void* ws, size_t bytes) {
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
   SMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   SMI_CHECK(!p.geglu_out || gemm_geglu_supported(p), "gemm: fused GEGLU not available for this shape/layout");
+  // SMI_SPLITK_DEBUG (tools/bench_splitk.py): slice count and slice-kernel variant of THIS call from SMI_SPLITK_S / _V
+  static const bool splitk_debug = getenv("SMI_SPLITK_DEBUG") != nullptr;
+  if (splitk_debug && gemm2_supported(p) && !p.geglu_out) {
+    const char* es = getenv("SMI_SPLITK_S");
+    const char* ev = getenv("SMI_SPLITK_V");
+    const int S = es ? atoi(es) : 0, V = ev ? atoi(ev) : 0;
+    if (S > 1 && t_scratch && (size_t)S * p.M * p.N * sizeof(float) <= t_scratch_bytes) return launch_splitk(p, S, stream, V);
+    if (S == 1) return launch_gemm2(p, V, stream);
+  }
   if (gemm_mode() != 3) {
     const int S = splitk_slices(p);
     if (S > 1) return launch_splitk(p, S, stream);

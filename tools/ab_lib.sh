@@ -12,7 +12,7 @@ for r in $(seq 1 $ROUNDS); do
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 pre = d.get("preroll") or {}
-print(f"{sys.argv[1]:5s} {d['config']['workload']}: {d['ms_per_step']:.2f} ms/step, pre-roll {pre.get('ms', float('nan')):.1f} ms, frac {d['roofline']['frac']:.3f}", flush=True)
+print(f"{sys.argv[1]:5s} {d['config']['workload']}: {d['ms_per_step']:.2f} ms/step, pre-roll {pre.get('ms', float('nan')):.1f} ms (guidance 1: {pre.get('ms_at_guidance_1') or float('nan'):.1f}), frac {d['roofline']['frac']:.3f}", flush=True)
 P
   done
 done
