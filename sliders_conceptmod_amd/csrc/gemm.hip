@@ -645,13 +645,24 @@ int splitk_slices(const GemmParams& p) {
   if (nk < long_k && tiles > few_tiles) return 1;
   int64_t lim = 16;
   const int64_t budget = 512;  // workgroup-tiles per launch after the split (two per CU)
-  if (budget / tiles < lim) lim = budget / tiles;
   if (nk / 4 < lim) lim = nk / 4;
   const int64_t fit = (int64_t)(t_scratch_bytes / ((size_t)p.M * p.N * sizeof(float)));
   if (fit < lim) lim = fit;
-  int s = 1;
-  while (2 * s <= lim) s *= 2;
-  return s;
+  static const bool pow2 = []() { const char* e = getenv("SMI_SPLITK_POW2"); return e && e[0] == '1'; }();
+  if (pow2) {  // rounds 3: the largest power of two that keeps the 128 x 128 tiles within the budget
+    if (budget / tiles < lim) lim = budget / tiles;
+    int s = 1;
+    while (2 * s <= lim) s *= 2;
+    return s;
+  }
+  // Any slice count, chosen to FILL the budget with the slice kernel launch_splitk will take: 64 x 128 tiles when two or
+  // more slices of them fit, else 128 x 128.  2048 x 1280 x 5120 (160 tiles): two slices were 320 workgroups on 256 CUs
+  // (50.7 us), three are 480 (43.7); 2048 x 640 x 2560: four slices of 128 x 128 (320 workgroups, 22.9 us) -> three of
+  // 64 x 128 (480, 21.0); 1024 x 1280 x 5120: 31.2 -> 29.8 (tools/bench_splitk.py q).
+  const int64_t tiles64 = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128);
+  int64_t s = budget / tiles64 < lim ? budget / tiles64 : lim;
+  if (s < 2) s = budget / tiles < lim ? budget / tiles : lim;
+  return s < 1 ? 1 : (int)s;
 }
 int launch_splitk(const GemmParams& p, int S, hipStream_t stream, int variant = -1) {
   if (p.conv) {
@@ -679,7 +690,10 @@ int launch_splitk(const GemmParams& p, int S, hipStream_t stream, int variant = 
 #define FIN_T(TT_)                   \
   do {                               \
     if (S == 2) FIN(TT_, 2);         \
+    else if (S == 3) FIN(TT_, 3);    \
     else if (S == 4) FIN(TT_, 4);    \
+    else if (S == 5) FIN(TT_, 5);    \
+    else if (S == 6) FIN(TT_, 6);    \
     else if (S == 8) FIN(TT_, 8);    \
     else if (S == 16) FIN(TT_, 16);  \
     else FIN(TT_, 0);                \

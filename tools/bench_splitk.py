@@ -2,7 +2,7 @@
 kernel) pair against the library's own choice.  Needs SMI_SPLITK_DEBUG=1 in the environment (set below before the library
 loads): launch_gemm then takes the slice count and the gemm2 variant of each call from SMI_SPLITK_S / SMI_SPLITK_V.
 
-    python tools/bench_splitk.py [xl2|xl4|sd14|all]
+    python tools/bench_splitk.py [xl2|xl4|sd14|q|all]   (SPLITK_SLICES=1,2,3,4,6 SPLITK_VARIANTS=5,7 narrow the sweep)
 """
 import ctypes as C
 import os
@@ -21,10 +21,16 @@ SHAPES = {
             (2048, 1280, 5120, 1, 0), (8192, 640, 640, 1, 0), (8192, 1920, 640, 0, 4), (8192, 640, 2560, 1, 0)],
     "xl4": [(4096, 1280, 1280, 0, 0), (4096, 1280, 1280, 1, 0), (4096, 1280, 1280, 1, 4), (4096, 3840, 1280, 0, 4),
             (4096, 1280, 5120, 1, 0), (16384, 640, 640, 1, 0), (16384, 640, 2560, 1, 0)],
+    "q": [(2048, 1280, 5120, 1, 0), (2048, 1280, 5120, 1, 4), (4096, 1280, 5120, 1, 0), (2048, 640, 2560, 1, 0),
+          (512, 1280, 5120, 1, 0), (1024, 1280, 5120, 1, 0), (1024, 1280, 1280, 1, 0)],
     "sd14": [(8192, 320, 320, 1, 0), (8192, 960, 320, 0, 4), (8192, 320, 1280, 1, 0), (2048, 640, 640, 1, 0),
              (2048, 1920, 640, 0, 4), (2048, 640, 2560, 1, 0), (512, 1280, 1280, 1, 0), (512, 3840, 1280, 0, 4),
              (512, 1280, 5120, 1, 0), (128, 1280, 1280, 1, 0)],
 }
+
+
+SLICES = tuple(int(x) for x in os.environ.get("SPLITK_SLICES", "1,2,4,8").split(","))
+VARIANTS = tuple(int(x) for x in os.environ.get("SPLITK_VARIANTS", "5,7,10,12,11").split(","))
 
 
 def timeit(fn, iters=30):
@@ -70,10 +76,10 @@ def main():
             t_def, c_def = run(0, 0)
             line = [f"{name} M={M:5d} N={N:4d} K={K:4d} epi={epi} r={r}: default {t_def:6.1f} us |"]
             best = (t_def, "default")
-            for S in (1, 2, 4, 8):
+            for S in SLICES:
                 if S > 1 and K // 64 // S < 2:
                     continue
-                for V in (5, 7, 10, 12, 11):
+                for V in VARIANTS:
                     if V in (10, 12, 11) and N % 160:
                         continue
                     if V == 11 and S > 1:
