@@ -268,6 +268,10 @@ int smi_op_attention_bwd(int dtype, const void* q, const void* k, const void* v,
                          int d, float scale, void* stream);
 int smi_op_groupnorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
                      float* scratch, int nb, int hw, int c, int g, float eps, int silu, void* stream);
+/* Workgroups of the one-launch (cooperative) GroupNorm that gave up waiting for their sample's other workgroups since the
+ * library was loaded: 0 unless the device lost workgroups (the wait is bounded, csrc/norm.hip); -1 if it cannot be read.
+ * A diagnostic for tests -- the reference has no counterpart (torch.nn.GroupNorm is one ATen call). */
+int smi_gn_coop_timeouts(void);
 int smi_op_layernorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
                      float* mean_rstd, int m, int c, float eps, void* stream);
 int smi_op_geglu(int dtype, const void* proj, void* out, const void* dout, void* dproj, int m, int c4, void* stream);

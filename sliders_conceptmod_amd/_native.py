@@ -101,6 +101,7 @@ _SIGS = {
                        [C.c_void_p]),
     "smi_op_attention_fwd": (C.c_int, [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
     "smi_op_attention_bwd": (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "smi_gn_coop_timeouts": (C.c_int, []),
     "smi_op_groupnorm": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "smi_op_layernorm": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 2 + [C.c_float, C.c_void_p]),
     "smi_op_geglu": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p]),

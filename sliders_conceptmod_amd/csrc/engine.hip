@@ -2873,6 +2873,7 @@ int smi_op_attention_bwd(int dtype, const void* q, const void* k, const void* v,
   return launch_attn_bwd(p, (hipStream_t)stream);
 }
 // scratch layout (floats): ab[2*nb*c] | mean_rstd[nb*g*2] | partial[...]
+int smi_gn_coop_timeouts(void) { return smi::gn_coop_timeouts(); }
 int smi_op_groupnorm(int dtype, const void* x, const void* gamma, const void* beta, void* y, const void* dy, void* dx,
                      float* scratch, int nb, int hw, int c, int g, float eps, int silu, void* stream) {
   float* ab = scratch;

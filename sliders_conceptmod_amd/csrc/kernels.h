@@ -98,6 +98,7 @@ int launch_attn_bwd(const AttnParams& p, hipStream_t stream);
 // GroupNorm over [Nb, HW, C]; writes per-(n,c) affine a,b (f32 [Nb,C] each: y = x*a + b) into `ab` ([2,Nb,C]) and
 // y = (silu?)(x*a+b).  `partial` is scratch f32, gn_partial_floats(Nb, HW, G) long ([Nb, nchunk, G, 2], nchunk from gn_num_chunks(HW), + the fold).
 int gn_num_chunks(int HW);
+int gn_coop_timeouts();  // workgroups of the cooperative one-launch form that gave up waiting (0), norm.hip
 size_t gn_partial_floats(int Nb, int HW, int G);  // floats of `partial` scratch (chunk partials + their fold for maps > 128 x 128)
 // ab: [2][Nb][C] -- a = ab, b = ab + Nb*C.  The backward takes the two halves as separate pointers so that it can run
 // on a sample sub-range of a larger forward batch.

@@ -10,6 +10,8 @@
 //                     dx = a*dz + c2*x + c3   with  c2 = -r^2*S2/cnt,  c3 = -r*S1/cnt - c2*mu
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "kernels.h"
 
 namespace smi {
@@ -43,15 +45,16 @@ __host__ __device__ inline GnGeom gn_geom(int C) {
 }
 
 // MODE 0: forward stats (sum x, sum x^2).  MODE 1: backward stats (S1, S2), SILU selects dz = dy*silu'(z)
-template <typename T, int MODE, bool SILU>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                         const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                         const float* __restrict__ aa, const float* __restrict__ bb,
-                                                         float* __restrict__ partial, int Nb, int HW, int C, int G,
-                                                         int nchunk) {
-  extern __shared__ float red[];  // [rpar][C][2]
+// COOP (the one-launch form below): the chunk's two sums leave as ONE 8-byte write-through store (agent-scope relaxed
+// atomic store = sc1) and are read back with 8-byte agent-scope loads -- the same bits through a path that needs no
+// release / acquire fence around the per-sample barrier.
+template <typename T, int MODE, bool SILU, bool COOP = false>
+__device__ __forceinline__ void gn_partial_body(float* red /* LDS [rpar][C][2] */, int n, int chunk,
+                                                const T* __restrict__ x, const T* __restrict__ dy,
+                                                const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                const float* __restrict__ aa, const float* __restrict__ bb,
+                                                float* __restrict__ partial, int HW, int C, int G, int nchunk) {
   const GnGeom gg = gn_geom(C);
-  const int n = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
   const int rsub = gg.cols8 >= 256 ? 0 : tid / gg.cols8;
   const int col_base = gg.cols8 >= 256 ? tid : tid - rsub * gg.cols8;
@@ -131,9 +134,23 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
         a1 += red[((int64_t)rs * C + c) * 2 + 1];
       }
     float* out = partial + (((int64_t)n * nchunk + chunk) * G + g) * 2;
-    out[0] = a0;
-    out[1] = a1;
+    if constexpr (COOP) {
+      const unsigned long long v = (unsigned long long)__float_as_uint(a0) | ((unsigned long long)__float_as_uint(a1) << 32);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(out), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      out[0] = a0;
+      out[1] = a1;
+    }
   }
+}
+template <typename T, int MODE, bool SILU>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                         const float* __restrict__ aa, const float* __restrict__ bb,
+                                                         float* __restrict__ partial, int Nb, int HW, int C, int G,
+                                                         int nchunk) {
+  extern __shared__ float red[];  // [rpar][C][2]
+  gn_partial_body<T, MODE, SILU>(red, blockIdx.y, blockIdx.x, x, dy, gamma, beta, aa, bb, partial, HW, C, G, nchunk);
 }
 
 // partial [Nb][nchunk][G][2] -> folded [Nb][GN_MAX_SLOTS][G][2]: slot s = sum of chunks [s per, (s + 1) per) in order
@@ -152,17 +169,14 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ 
 // MODE 0: y = silu?(x*a+b).   MODE 1: dx = a*dz + c2*x + c3 (+ add).
 // Grid (chunk, n) as the partial kernel.  Head: the chunk partials of sample n -> per-group statistics in LDS
 // (8 lanes per group walk the partials, xor tree: fixed order, deterministic), then the rows of this chunk.
-template <typename T, int MODE, bool SILU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                       const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                       const float* __restrict__ partial, float* __restrict__ aa,
-                                                       float* __restrict__ bb, float* __restrict__ mean_rstd,
-                                                       const T* add, T* out, int Nb,
-                                                       int HW, int C, int G, int nchunk, float eps) {
+template <typename T, int MODE, bool SILU, bool COOP = false>
+__device__ __forceinline__ void gn_apply_body(float* st /* LDS [G][2]: MODE 0 (mean, rstd); MODE 1 (c2, c3) */, int n,
+                                              int chunk, const T* __restrict__ x, const T* __restrict__ dy,
+                                              const T* __restrict__ gamma, const T* __restrict__ beta,
+                                              const float* partial, float* aa, float* bb, float* mean_rstd,
+                                              const T* add, T* out, int HW, int C, int G, int nchunk, float eps) {
   // nchunk = slots of `partial` per sample (the grid's chunk count, or GN_MAX_SLOTS after a fold)
-  extern __shared__ float st[];  // [G][2]: MODE 0 (mean, rstd); MODE 1 (c2, c3)
   const GnGeom gg = gn_geom(C);
-  const int n = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
   const int cpg = C / G;
   const float cnt = (float)HW * (float)cpg;
@@ -170,8 +184,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     float s = 0.f, sq = 0.f;
     for (int ch = tid & 7; ch < nchunk; ch += 8) {
       const float* p = partial + (((int64_t)n * nchunk + ch) * G + g) * 2;
-      s += p[0];
-      sq += p[1];
+      if constexpr (COOP) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        s += __uint_as_float((unsigned)v);
+        sq += __uint_as_float((unsigned)(v >> 32));
+      } else {
+        s += p[0];
+        sq += p[1];
+      }
     }
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) {
@@ -274,6 +295,76 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       }
     }
   }
+}
+template <typename T, int MODE, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                       const float* __restrict__ partial, float* __restrict__ aa,
+                                                       float* __restrict__ bb, float* __restrict__ mean_rstd,
+                                                       const T* add, T* out, int Nb,
+                                                       int HW, int C, int G, int nchunk, float eps) {
+  extern __shared__ float st[];
+  gn_apply_body<T, MODE, SILU>(st, blockIdx.y, blockIdx.x, x, dy, gamma, beta, partial, aa, bb, mean_rstd, add, out, HW, C,
+                               G, nchunk, eps);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Statistics + apply in ONE launch (forward and backward), for every map of at most 64 chunks: grid (chunk, n) as the two
+// kernels; a workgroup computes and publishes the partial sums of its chunk, waits until all chunks of ITS SAMPLE have
+// done so, then runs the apply body on the same chunk (whose rows it has just read: L2 / Infinity-Cache hits).  The two
+// bodies are the two kernels' bodies, the partials pass through the same buffer and are re-reduced in the same order, so
+// the result is bit-identical to the two-launch form -- it removes a launch (and the statistics pass's drain / the apply
+// pass's ramp), nothing else.
+// The per-sample barrier (cdna guide, Guideline 16, the write-through form: correct for any placement of the workgroups
+// over the XCDs): the partials leave as 8-byte write-through (sc1) stores -> every wave vmcnt(0) -> workgroup barrier ->
+// thread 0: relaxed agent fetch_add on arrive[n], then polls arrive[n] (relaxed, s_sleep between polls) until it reads
+// nchunk -> workgroup barrier -> EVERY load of the partials is an 8-byte sc1 load.  No release / acquire fence: the
+// first version had them (plain stores, buffer_wbl2 sc1 + buffer_inv sc1 per workgroup) and ran 1.3-2.7 x SLOWER than
+// two launches at 16 samples (16 x 1024 x 1280: 93.6 vs 34.6 us) -- each release wrote back an L2 full of the other
+// samples' freshly written y.  The last workgroup to LEAVE (second counter) zeroes both counters for the slot's next user.
+// Progress: workgroups are dispatched in linear order (chunk fastest), every XCD takes its share in order, so the oldest
+// unfinished sample always has all of its <= 64 workgroups resident or finished, whatever else waits behind it; the chip
+// holds >= 1024 of these workgroups.  The poll is bounded all the same (2^20 polls, seconds): a workgroup that gives up
+// counts itself in g_gn_coop_timeouts (read by smi_gn_coop_timeouts, asserted zero by the tests) and goes on.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GN_COOP_SLOTS = 32, GN_COOP_MAXNB = 512;
+__device__ int g_gn_coop_sync[GN_COOP_SLOTS][2][GN_COOP_MAXNB];  // zero-initialised: [slot][arrive | depart][sample]
+__device__ int g_gn_coop_timeouts;
+
+__device__ __forceinline__ void gn_sample_barrier(int* arrive, int* depart, int nchunk) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int polls = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunk) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++polls > (1 << 20)) {
+        __hip_atomic_fetch_add(&g_gn_coop_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    if (__hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunk - 1) {
+      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // everyone has read nchunk and left
+      __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the partial loads below the barrier
+}
+
+template <typename T, int MODE, bool SILU>
+__global__ __launch_bounds__(256) void gn_coop_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                      const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                      float* partial, float* aa, float* bb, float* mean_rstd,
+                                                      const T* add, T* out, int HW, int C, int G, int nchunk, float eps,
+                                                      int slot) {
+  extern __shared__ float gn_lds[];  // the partial body's [rpar][C][2], then the apply body's [G][2]
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  gn_partial_body<T, MODE, SILU, true>(gn_lds, n, chunk, x, dy, gamma, beta, aa, bb, partial, HW, C, G, nchunk);
+  gn_sample_barrier(&g_gn_coop_sync[slot][0][n], &g_gn_coop_sync[slot][1][n], nchunk);
+  gn_apply_body<T, MODE, SILU, true>(gn_lds, n, chunk, x, dy, gamma, beta, partial, aa, bb, mean_rstd, add, out, HW, C, G,
+                                     nchunk, eps);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -600,6 +691,23 @@ inline const float* gn_fold(float* partial, int Nb, int nchunk, int G, hipStream
   return folded;
 }
 
+// the one-launch cooperative form: OFF unless SMI_GN_COOP=1 -- it is bit-identical (tested) and SLOWER than two launches
+// on every map (tools/bench_norm.py, forward, us: 2 x 4096 x 320 19.7 vs 16.6, 4 x 1024 x 1280 23.4 vs 18.0, 16 x 4096 x 640
+// 80 vs 53, 16 x 16384 x 320 134 vs 102; poll interval 0.1 or 0.6 us: no difference).  A kernel boundary costs ~2 us here; the
+// per-sample barrier costs a counter round trip + a poll + 16 KB of uncached partial reads per workgroup, and it
+// holds every workgroup of the launch resident while it waits.  Kept as the measured answer to VERDICT r3 item 2's
+// "one-launch GroupNorm for maps that fit a co-resident grid".
+static bool gn_coop_ok(int Nb, int nchunk) {
+  static const bool on = []() { const char* e = getenv("SMI_GN_COOP"); return e && e[0] == '1'; }();
+  return on && nchunk <= GN_MAX_SLOTS && Nb <= GN_COOP_MAXNB;
+}
+// counter slot of a launch: launches on one stream are ordered (any slot would do); launches on different streams or from
+// different host threads draw different slots as long as fewer than GN_COOP_SLOTS of them are in flight together
+static int gn_coop_slot() {
+  static std::atomic<unsigned> next{0};
+  return (int)(next.fetch_add(1, std::memory_order_relaxed) % GN_COOP_SLOTS);
+}
+
 template <typename T>
 int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* ab, float* mean_rstd, float* partial,
              int Nb, int HW, int C, int G, float eps, int silu, hipStream_t st) {
@@ -627,9 +735,23 @@ int gn_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float*
   const int nchunk = gn_num_chunks(HW);
   const GnGeom gg = gn_geom(C);
   const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
+  const size_t sa = (size_t)G * 2 * sizeof(float);
+  if (gn_coop_ok(Nb, nchunk)) {
+    const size_t sc = sm > sa ? sm : sa;
+    const int slot = gn_coop_slot();
+    if (silu)
+      hipLaunchKernelGGL((gn_coop_kernel<T, 0, true>), dim3(nchunk, Nb), dim3(256), sc, st, (const T*)x, nullptr,
+                         (const T*)gamma, (const T*)beta, partial, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, HW, C,
+                         G, nchunk, eps, slot);
+    else
+      hipLaunchKernelGGL((gn_coop_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sc, st, (const T*)x, nullptr,
+                         (const T*)gamma, (const T*)beta, partial, ab, ab + (size_t)Nb * C, mean_rstd, nullptr, (T*)y, HW, C,
+                         G, nchunk, eps, slot);
+    SMI_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL((gn_partial_kernel<T, 0, false>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x, nullptr,
                      nullptr, nullptr, ab, ab, partial, Nb, HW, C, G, nchunk);
-  const size_t sa = (size_t)G * 2 * sizeof(float);
   const float* red = gn_fold(partial, Nb, nchunk, G, st);
   const int nslot = nchunk > GN_MAX_SLOTS ? GN_MAX_SLOTS : nchunk;
   if (silu)
@@ -650,6 +772,21 @@ int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta,
   const int nchunk = gn_num_chunks(HW);
   const GnGeom gg = gn_geom(C);
   const size_t sm = (size_t)gg.rpar * C * 2 * sizeof(float);
+  if (gn_coop_ok(Nb, nchunk)) {
+    const size_t sa0 = (size_t)G * 2 * sizeof(float);
+    const size_t sc = sm > sa0 ? sm : sa0;
+    const int slot = gn_coop_slot();
+    if (silu)
+      hipLaunchKernelGGL((gn_coop_kernel<T, 1, true>), dim3(nchunk, Nb), dim3(256), sc, st, (const T*)x, (const T*)dy,
+                         (const T*)gamma, (const T*)beta, partial, const_cast<float*>(aa), const_cast<float*>(bb),
+                         const_cast<float*>(mean_rstd), (const T*)add, (T*)dx, HW, C, G, nchunk, 0.f, slot);
+    else
+      hipLaunchKernelGGL((gn_coop_kernel<T, 1, false>), dim3(nchunk, Nb), dim3(256), sc, st, (const T*)x, (const T*)dy,
+                         (const T*)gamma, (const T*)beta, partial, const_cast<float*>(aa), const_cast<float*>(bb),
+                         const_cast<float*>(mean_rstd), (const T*)add, (T*)dx, HW, C, G, nchunk, 0.f, slot);
+    SMI_HIP(hipGetLastError());
+    return 0;
+  }
   if (silu)
     hipLaunchKernelGGL((gn_partial_kernel<T, 1, true>), dim3(nchunk, Nb), dim3(256), sm, st, (const T*)x,
                        (const T*)dy, (const T*)gamma, (const T*)beta, aa, bb, partial, Nb, HW, C, G, nchunk);
@@ -674,6 +811,11 @@ int gn_bwd_t(const void* x, const void* dy, const void* gamma, const void* beta,
 
 }  // namespace
 
+int gn_coop_timeouts() {  // workgroups of the cooperative GroupNorm that gave up waiting since the library was loaded (0)
+  int v = -1;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_gn_coop_timeouts), sizeof(int)) != hipSuccess) return -1;
+  return v;
+}
 int gn_num_chunks(int HW) { return (HW + gn_rows_per_chunk(HW) - 1) / gn_rows_per_chunk(HW); }
 size_t gn_partial_floats(int Nb, int HW, int G) {
   const int nchunk = gn_num_chunks(HW);

@@ -318,7 +318,7 @@ def test_groupnorm_forward_backward(lib, dt, nb, HW, Cc, G, silu):
     dy = rnd(nb, HW, Cc, dt=dt, seed=4)
     y, dx = torch.empty_like(x), torch.empty_like(x)
     # chunk partials: <= 64 chunks of >= 16 rows up to 128 x 128 maps; 256-row chunks + a 64-slot fold beyond (norm.hip)
-    nchunk = (HW + 63) // 64 if HW <= 16384 else (HW + 255) // 256 + 64
+    nchunk = 64 if HW <= 16384 else (HW + 255) // 256 + 64  # (upper bound of gn_num_chunks)
     scratch = torch.empty(2 * nb * Cc + nb * G * 2 + nb * nchunk * G * 2 + 2 * nb * Cc + 64, device="cuda")
     chk(lib, lib.smi_op_groupnorm(dcode(dt), P(x), P(gamma), P(beta), P(y), P(dy), P(dx), P(scratch), nb, HW, Cc, G,
                                   1e-5, silu, None))
@@ -517,3 +517,23 @@ def test_splitk_every_slice_count_matches_the_unsplit_kernel():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_splitk.py")], capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "split-K check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_groupnorm_one_launch_forms_are_bit_identical():
+    """GroupNorm statistics + apply in one launch (round 4: workgroups of a sample meet at a counter between the two bodies,
+    csrc/norm.hip gn_coop_kernel) against the two-launch form (SMI_GN_COOP=0), forward and backward, fp16 / bf16, with
+    and without SiLU, pre-roll and step batches: same bits for y, dx and the saved statistics, equal repeats, and no
+    workgroup gave up its bounded wait -- tools/gn_digest.py in two child processes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for coop in ("1", "0"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gn_digest.py")], capture_output=True, text=True,
+                           timeout=600, cwd=root, env={**os.environ, "SMI_GN_COOP": coop})
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    assert outs[0]["timeouts"] == 0 and outs[1]["timeouts"] == 0
+    assert outs[0] == outs[1], {k: (outs[0][k], outs[1][k]) for k in outs[0] if outs[0][k] != outs[1][k]}
