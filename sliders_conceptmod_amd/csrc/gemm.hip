@@ -687,16 +687,16 @@ int launch_splitk(const GemmParams& p, int S, hipStream_t stream, int variant = 
   const int64_t total = (int64_t)p.M * (p.N / 4);
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
 #define FIN(TT_, NS_) hipLaunchKernelGGL((splitk_finish_kernel<TT_, NS_>), dim3(grid), dim3(256), 0, stream, p, (const float*)t_scratch, S)
-#define FIN_T(TT_)                   \
-  do {                               \
-    if (S == 2) FIN(TT_, 2);         \
-    else if (S == 3) FIN(TT_, 3);    \
-    else if (S == 4) FIN(TT_, 4);    \
-    else if (S == 5) FIN(TT_, 5);    \
-    else if (S == 6) FIN(TT_, 6);    \
-    else if (S == 8) FIN(TT_, 8);    \
-    else if (S == 16) FIN(TT_, 16);  \
-    else FIN(TT_, 0);                \
+#define FIN_T(TT_)                                                                                              \
+  do {                                                                                                          \
+    switch (S) {                                                                                                \
+      case 2: FIN(TT_, 2); break;   case 3: FIN(TT_, 3); break;   case 4: FIN(TT_, 4); break;                   \
+      case 5: FIN(TT_, 5); break;   case 6: FIN(TT_, 6); break;   case 7: FIN(TT_, 7); break;                   \
+      case 8: FIN(TT_, 8); break;   case 9: FIN(TT_, 9); break;   case 10: FIN(TT_, 10); break;                 \
+      case 11: FIN(TT_, 11); break; case 12: FIN(TT_, 12); break; case 13: FIN(TT_, 13); break;                 \
+      case 14: FIN(TT_, 14); break; case 15: FIN(TT_, 15); break; case 16: FIN(TT_, 16); break;                 \
+      default: FIN(TT_, 0);                                                                                     \
+    }                                                                                                           \
   } while (0)
   if (p.dtype == DT_F16) FIN_T(f16); else FIN_T(bf16);
 #undef FIN_T

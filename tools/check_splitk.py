@@ -44,7 +44,7 @@ def main():
         e0 = ((base - ref).abs().max() / ref.abs().max()).item()
         assert e0 < 2e-5, (M, N, K, "un-split vs torch", e0)
         base16 = run(1, 5, False)
-        for S in (2, 3, 4, 5, 6, 7, 8, 16):
+        for S in (2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 16):
             if K // 64 // S < 1:
                 continue
             for V in (5, 7):
